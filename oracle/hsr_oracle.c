@@ -1,0 +1,804 @@
+/*
+ * hsr_oracle.c — CPU restatement of the Hier-SLAM differentiable Gaussian rasterizer.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load this library, and there only
+ * as the checker / reported CPU baseline.  The product path (hier-slam_amd/) never links, imports
+ * or calls it and fails loudly when its HIP library is missing.
+ *
+ * PARITY UNPINNED.  The reference (LeeBY68/Hier-SLAM, hierslam-diff-gaussian-rasterization-w-depth)
+ * holds no tests, golden vectors or fixtures for this path and its kernels are
+ * CUDA (nvcc, cooperative_groups, cub): unbuildable in this image, so no reference output exists to
+ * pin this file against.  It is an independent plain-C restatement written from the behaviour of the
+ * reference source; every function cites the reference file:line it follows
+ * (paths relative to hierslam-diff-gaussian-rasterization-w-depth/cuda_rasterizer/).  What pins it
+ * instead (tests/): a float64 dense torch.autograd restatement of the forward maths, finite
+ * differences, and the algebraic identities the compositing satisfies.
+ *
+ * Floating-point policy: everything that decides an INTEGER output (radii, tile rects, tiles_touched,
+ * sort keys, ranges) is evaluated in the reference's exact operation order, fp32 (double where the
+ * reference promotes), with contraction disabled (build with -ffp-contract=off).
+ *
+ * Gradient accumulation: the reference sums per-(pixel, Gaussian) terms with fp32 atomicAdd in
+ * arbitrary order (backward.cu:616-663, :828-896).  Here each per-pair term is computed in fp32
+ * exactly as the reference does and the per-Gaussian sum is kept in double, rounded to fp32 once:
+ * order-independent, and within the reference's own fp32 noise of any of its summation orders.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BLOCK_X 16
+#define BLOCK_Y 16
+#define BLOCK_SIZE (BLOCK_X * BLOCK_Y)
+#define NUM_CHANNELS 3 /* config.h:15 */
+
+/* auxiliary.h:21-37 */
+static const float SH_C0 = 0.28209479177387814f;
+static const float SH_C1 = 0.4886025119029199f;
+static const float SH_C2[] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                              -1.0925484305920792f, 0.5462742152960396f};
+static const float SH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                              0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                              -0.5900435899266435f};
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+/* GLM-style column-major 3x3: m.c[col][row] (glm/detail/type_mat3x3.inl) */
+typedef struct { float c[3][3]; } m3;
+
+static inline float fminf_(float a, float b) { return a < b ? a : b; }
+static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
+
+/* glm mat3*mat3, element sums left to right (third_party/glm/glm/detail/type_mat3x3.inl:486-520) */
+static m3 m3_mul(const m3* a, const m3* b)
+{
+    m3 r;
+    for (int c = 0; c < 3; c++)
+        for (int rr = 0; rr < 3; rr++)
+            r.c[c][rr] = a->c[0][rr] * b->c[c][0] + a->c[1][rr] * b->c[c][1] + a->c[2][rr] * b->c[c][2];
+    return r;
+}
+static m3 m3_transpose(const m3* a)
+{
+    m3 r;
+    for (int c = 0; c < 3; c++)
+        for (int rr = 0; rr < 3; rr++) r.c[c][rr] = a->c[rr][c];
+    return r;
+}
+/* glm::mat3(a0..a8): column-major fill */
+static m3 m3_make(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8)
+{
+    m3 r;
+    r.c[0][0] = a0; r.c[0][1] = a1; r.c[0][2] = a2;
+    r.c[1][0] = a3; r.c[1][1] = a4; r.c[1][2] = a5;
+    r.c[2][0] = a6; r.c[2][1] = a7; r.c[2][2] = a8;
+    return r;
+}
+
+/* auxiliary.h:58-66 */
+static v3 transformPoint4x3(v3 p, const float* m)
+{
+    v3 t = {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+            m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
+    return t;
+}
+/* auxiliary.h:68-77 */
+static v4 transformPoint4x4(v3 p, const float* m)
+{
+    v4 t = {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+            m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14],
+            m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]};
+    return t;
+}
+/* auxiliary.h:89-97 */
+static v3 transformVec4x3Transpose(v3 p, const float* m)
+{
+    v3 t = {m[0] * p.x + m[1] * p.y + m[2] * p.z,
+            m[4] * p.x + m[5] * p.y + m[6] * p.z,
+            m[8] * p.x + m[9] * p.y + m[10] * p.z};
+    return t;
+}
+/* auxiliary.h:41-44: double arithmetic, rounded to float on return */
+static float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+/* auxiliary.h:46-56 */
+static void getRect(float px, float py, int max_radius, uint32_t* rminx, uint32_t* rminy,
+                    uint32_t* rmaxx, uint32_t* rmaxy, uint32_t gx, uint32_t gy)
+{
+    int a;
+    a = (int)((px - max_radius) / BLOCK_X); if (a < 0) a = 0; *rminx = (uint32_t)a < gx ? (uint32_t)a : gx;
+    a = (int)((py - max_radius) / BLOCK_Y); if (a < 0) a = 0; *rminy = (uint32_t)a < gy ? (uint32_t)a : gy;
+    a = (int)((px + max_radius + BLOCK_X - 1) / BLOCK_X); if (a < 0) a = 0; *rmaxx = (uint32_t)a < gx ? (uint32_t)a : gx;
+    a = (int)((py + max_radius + BLOCK_Y - 1) / BLOCK_Y); if (a < 0) a = 0; *rmaxy = (uint32_t)a < gy ? (uint32_t)a : gy;
+}
+
+/* auxiliary.h:107-118 */
+static v3 dnormvdv3(v3 v, v3 dv)
+{
+    float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    v3 r;
+    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+    return r;
+}
+
+/* rasterizer_impl.cu:35-50 */
+uint32_t hsro_get_higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+/* auxiliary.h:139-164 (prefiltered trap omitted: the oracle has no device to trap) */
+static int in_frustum(int idx, const float* pts, const float* view, const float* proj, v3* p_view)
+{
+    v3 p = {pts[3 * idx], pts[3 * idx + 1], pts[3 * idx + 2]};
+    (void)proj; /* p_hom / p_proj are computed but unused by the reference's test */
+    *p_view = transformPoint4x3(p, view);
+    return !(p_view->z <= 0.2f);
+}
+
+/* rasterizer_impl.cu:54-66, :141-153 */
+void hsro_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present)
+{
+    for (int i = 0; i < P; i++) { v3 pv; present[i] = (uint8_t)in_frustum(i, means3D, view, proj, &pv); }
+}
+
+/* forward.cu:20-71 */
+static v3 computeColorFromSH(int idx, int deg, int max_coeffs, const float* means, const float* campos,
+                             const float* shs, uint8_t* clamped)
+{
+    v3 pos = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
+    v3 dir = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
+    float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+    dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+    const float* sh = shs + (size_t)idx * max_coeffs * 3;
+    float res[3];
+    float x = dir.x, y = dir.y, z = dir.z;
+    for (int c = 0; c < 3; c++) {
+#define SH(i) sh[(i) * 3 + c]
+        float r = SH_C0 * SH(0);
+        if (deg > 0) {
+            r = r - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+                    SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
+                if (deg > 2) {
+                    r = r + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+                        SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                        SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                        SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+                        SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+                }
+            }
+        }
+#undef SH
+        r += 0.5f;
+        clamped[3 * idx + c] = (r < 0);
+        res[c] = r > 0.0f ? r : 0.0f;
+    }
+    v3 out = {res[0], res[1], res[2]};
+    return out;
+}
+
+/* forward.cu:118-152 */
+static void computeCov3D(v3 scale, float mod, v4 rot, float* cov3D)
+{
+    m3 S = m3_make(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    S.c[0][0] = mod * scale.x; S.c[1][1] = mod * scale.y; S.c[2][2] = mod * scale.z;
+    float r = rot.x, x = rot.y, y = rot.z, z = rot.w; /* not normalised: forward.cu:127 */
+    m3 R = m3_make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                   2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                   2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    m3 M = m3_mul(&S, &R);
+    m3 Mt = m3_transpose(&M);
+    m3 Sigma = m3_mul(&Mt, &M);
+    cov3D[0] = Sigma.c[0][0]; cov3D[1] = Sigma.c[0][1]; cov3D[2] = Sigma.c[0][2];
+    cov3D[3] = Sigma.c[1][1]; cov3D[4] = Sigma.c[1][2]; cov3D[5] = Sigma.c[2][2];
+}
+
+/* shared by forward.cu:74-113 and backward.cu:166-199: T = W*J and cov2D (before the +0.3) */
+static void cov2d_core(v3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy, const float* cov3D,
+                       const float* view, v3* t_out, float* txtz_o, float* tytz_o, m3* T_out, m3* Vrk_out, m3* cov_out)
+{
+    v3 t = transformPoint4x3(mean, view);
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    const float txtz = t.x / t.z, tytz = t.y / t.z;
+    t.x = fminf_(limx, fmaxf_(-limx, txtz)) * t.z;
+    t.y = fminf_(limy, fmaxf_(-limy, tytz)) * t.z;
+    m3 J = m3_make(focal_x / t.z, 0.0f, -(focal_x * t.x) / (t.z * t.z),
+                   0.0f, focal_y / t.z, -(focal_y * t.y) / (t.z * t.z), 0, 0, 0);
+    m3 W = m3_make(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    m3 T = m3_mul(&W, &J);
+    m3 Vrk = m3_make(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    m3 Tt = m3_transpose(&T), Vt = m3_transpose(&Vrk);
+    m3 A = m3_mul(&Tt, &Vt);
+    *cov_out = m3_mul(&A, &T);
+    *t_out = t; *txtz_o = txtz; *tytz_o = tytz; *T_out = T; *Vrk_out = Vrk;
+}
+
+typedef struct HsroState {
+    int P, W, H, K, semantic, R, tiles_x, tiles_y, has_sh, own_cov3d;
+    float* depths;          /* [P]   view-space z                         (GeometryState.depths)        */
+    float* means2D;         /* [P,2] pixel centre                         (GeometryState.means2D)       */
+    float* conic_opacity;   /* [P,4] conic xyz + opacity                  (GeometryState.conic_opacity) */
+    float* cov3D;           /* [P,6]                                      (GeometryState.cov3D)         */
+    float* rgb;             /* [P,3] SH colours                           (GeometryState.rgb)           */
+    uint8_t* clamped;       /* [P,3]                                      (GeometryState.clamped)       */
+    int* radii;             /* [P]                                                                      */
+    uint32_t* tiles_touched;/* [P]                                                                      */
+    uint32_t* point_offsets;/* [P] inclusive scan                                                       */
+    uint64_t *keys_unsorted, *keys; /* [R]                                (BinningState)                */
+    uint32_t *vals_unsorted, *vals; /* [R]                                                              */
+    uint32_t* ranges;       /* [T,2]                                      (ImageState.ranges)           */
+    float* final_T;         /* [N]                                        (ImageState.accum_alpha)      */
+    uint32_t* n_contrib;    /* [N]                                        (ImageState.n_contrib)        */
+} HsroState;
+
+void hsro_free(HsroState* s)
+{
+    if (!s) return;
+    free(s->depths); free(s->means2D); free(s->conic_opacity); free(s->cov3D); free(s->rgb); free(s->clamped);
+    free(s->radii); free(s->tiles_touched); free(s->point_offsets); free(s->keys_unsorted); free(s->keys);
+    free(s->vals_unsorted); free(s->vals); free(s->ranges); free(s->final_T); free(s->n_contrib);
+    free(s);
+}
+
+int hsro_num_rendered(const HsroState* s) { return s->R; }
+/* field ids for tests */
+const void* hsro_field(const HsroState* s, int id)
+{
+    switch (id) {
+    case 0: return s->depths; case 1: return s->means2D; case 2: return s->conic_opacity; case 3: return s->cov3D;
+    case 4: return s->rgb; case 5: return s->clamped; case 6: return s->radii; case 7: return s->tiles_touched;
+    case 8: return s->point_offsets; case 9: return s->keys_unsorted; case 10: return s->keys;
+    case 11: return s->vals_unsorted; case 12: return s->vals; case 13: return s->ranges; case 14: return s->final_T;
+    case 15: return s->n_contrib; default: return 0;
+    }
+}
+
+/* stable LSD radix sort of (u64 key, u32 value) pairs on bits [0, end_bit) — the contract of
+ * cub::DeviceRadixSort::SortPairs as called at rasterizer_impl.cu:307-312 / :570-575 */
+static void stable_sort_pairs(const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, size_t n, int end_bit)
+{
+    uint64_t* ka = (uint64_t*)malloc(sizeof(uint64_t) * (n ? n : 1));
+    uint32_t* va = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint64_t* kb = (uint64_t*)malloc(sizeof(uint64_t) * (n ? n : 1));
+    uint32_t* vb = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    memcpy(ka, kin, n * sizeof(uint64_t)); memcpy(va, vin, n * sizeof(uint32_t));
+    size_t* cnt = (size_t*)malloc(sizeof(size_t) * 65537);
+    for (int shift = 0; shift < end_bit; shift += 16) {
+        int bits = end_bit - shift < 16 ? end_bit - shift : 16;
+        uint64_t mask = ((uint64_t)1 << bits) - 1;
+        memset(cnt, 0, sizeof(size_t) * 65537);
+        for (size_t i = 0; i < n; i++) cnt[((ka[i] >> shift) & mask) + 1]++;
+        for (size_t d = 0; d < 65536; d++) cnt[d + 1] += cnt[d];
+        for (size_t i = 0; i < n; i++) { size_t d = (ka[i] >> shift) & mask; size_t o = cnt[d]++; kb[o] = ka[i]; vb[o] = va[i]; }
+        uint64_t* tk = ka; ka = kb; kb = tk; uint32_t* tv = va; va = vb; vb = tv;
+    }
+    memcpy(kout, ka, n * sizeof(uint64_t)); memcpy(vout, va, n * sizeof(uint32_t));
+    free(ka); free(va); free(kb); free(vb); free(cnt);
+}
+
+/*
+ * Forward.  Follows Rasterizer::forward (rasterizer_impl.cu:198-345) when `semantics == NULL`
+ * (outputs colour, depth, median depth, opacity, mask) and Rasterizer::forward_semantic
+ * (rasterizer_impl.cu:460-610) otherwise (colour, semantic[K], depth, median depth, opacity).
+ * All pointers are host pointers; absent optionals are NULL (the reference's `data_ptr()==nullptr`
+ * switches, rasterizer_impl.cu:588, forward.cu:205, :241).
+ * Returns a state handle (the reference's geom/binning/img buffers) or NULL on allocation failure.
+ */
+HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
+                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                        const float* cam_pos, float tan_fovx, float tan_fovy, float* out_color, float* out_semantic,
+                        float* out_depth, float* out_median_depth, float* out_opacity, float* out_mask, int* radii_out)
+{
+    (void)background; /* forward never composites the background (forward.cu:391-392, :530-531) */
+    HsroState* s = (HsroState*)calloc(1, sizeof(HsroState));
+    if (!s) return 0;
+    const int W = width, H = height;
+    const size_t N = (size_t)W * H;
+    s->P = P; s->W = W; s->H = H; s->K = K; s->semantic = semantics != 0;
+    s->tiles_x = (W + BLOCK_X - 1) / BLOCK_X; s->tiles_y = (H + BLOCK_Y - 1) / BLOCK_Y;
+    const uint32_t gx = (uint32_t)s->tiles_x, gy = (uint32_t)s->tiles_y;
+    const size_t Tn = (size_t)gx * gy;
+    size_t Pa = P ? (size_t)P : 1;
+    s->depths = (float*)calloc(Pa, 4); s->means2D = (float*)calloc(Pa * 2, 4); s->conic_opacity = (float*)calloc(Pa * 4, 4);
+    s->cov3D = (float*)calloc(Pa * 6, 4); s->rgb = (float*)calloc(Pa * 3, 4); s->clamped = (uint8_t*)calloc(Pa * 3, 1);
+    s->radii = (int*)calloc(Pa, 4); s->tiles_touched = (uint32_t*)calloc(Pa, 4); s->point_offsets = (uint32_t*)calloc(Pa, 4);
+    s->ranges = (uint32_t*)calloc(Tn * 2, 4); s->final_T = (float*)calloc(N, 4); s->n_contrib = (uint32_t*)calloc(N, 4);
+    s->has_sh = colors_precomp == 0; s->own_cov3d = cov3D_precomp == 0;
+
+    /* rasterizer_impl.cu:226-227 */
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+
+    /* ---- preprocessCUDA, forward.cu:155-256 ---- */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        s->radii[idx] = 0; s->tiles_touched[idx] = 0;
+        v3 p_view;
+        if (!in_frustum(idx, means3D, viewmatrix, projmatrix, &p_view)) continue;
+        v3 p_orig = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        v4 p_hom = transformPoint4x4(p_orig, projmatrix);
+        float p_w = 1.0f / (p_hom.w + 0.0000001f);
+        v3 p_proj = {p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w};
+        const float* cov3D;
+        if (cov3D_precomp) cov3D = cov3D_precomp + (size_t)idx * 6;
+        else {
+            v3 sc = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
+            v4 q = {rotations[4 * idx], rotations[4 * idx + 1], rotations[4 * idx + 2], rotations[4 * idx + 3]};
+            computeCov3D(sc, scale_modifier, q, s->cov3D + (size_t)idx * 6);
+            cov3D = s->cov3D + (size_t)idx * 6;
+        }
+        v3 t; float txtz, tytz; m3 T, Vrk, cv;
+        cov2d_core(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &t, &txtz, &tytz, &T, &Vrk, &cv);
+        cv.c[0][0] += 0.3f; cv.c[1][1] += 0.3f;                       /* forward.cu:110-111 */
+        const float cx = cv.c[0][0], cy = cv.c[0][1], cz = cv.c[1][1];
+        float det = (cx * cz - cy * cy);                                /* forward.cu:219 */
+        if (det == 0.0f) continue;
+        float det_inv = 1.f / det;
+        float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
+        float mid = 0.5f * (cx + cz);
+        float lambda1 = mid + sqrtf(fmaxf_(0.1f, mid * mid - det));
+        float lambda2 = mid - sqrtf(fmaxf_(0.1f, mid * mid - det));
+        float my_radius = ceilf(3.f * sqrtf(fmaxf_(lambda1, lambda2)));
+        float pix = ndc2Pix(p_proj.x, W), piy = ndc2Pix(p_proj.y, H);
+        uint32_t rminx, rminy, rmaxx, rmaxy;
+        getRect(pix, piy, (int)my_radius, &rminx, &rminy, &rmaxx, &rmaxy, gx, gy);
+        if ((rmaxx - rminx) * (rmaxy - rminy) == 0) continue;
+        if (colors_precomp == 0) {
+            v3 c = computeColorFromSH(idx, D, M, means3D, cam_pos, shs, s->clamped);
+            s->rgb[3 * idx] = c.x; s->rgb[3 * idx + 1] = c.y; s->rgb[3 * idx + 2] = c.z;
+        }
+        s->depths[idx] = p_view.z;
+        s->radii[idx] = (int)my_radius;
+        s->means2D[2 * idx] = pix; s->means2D[2 * idx + 1] = piy;
+        s->conic_opacity[4 * idx] = conx; s->conic_opacity[4 * idx + 1] = cony; s->conic_opacity[4 * idx + 2] = conz;
+        s->conic_opacity[4 * idx + 3] = opacities[idx];
+        s->tiles_touched[idx] = (rmaxy - rminy) * (rmaxx - rminx);
+    }
+    if (radii_out) memcpy(radii_out, s->radii, sizeof(int) * (size_t)P);
+
+    /* ---- InclusiveSum, rasterizer_impl.cu:281 / :544 ---- */
+    { uint32_t acc = 0; for (int i = 0; i < P; i++) { acc += s->tiles_touched[i]; s->point_offsets[i] = acc; } }
+    const int R = P > 0 ? (int)s->point_offsets[P - 1] : 0;          /* rasterizer_impl.cu:285 */
+    s->R = R;
+    size_t Ra = R ? (size_t)R : 1;
+    s->keys_unsorted = (uint64_t*)calloc(Ra, 8); s->keys = (uint64_t*)calloc(Ra, 8);
+    s->vals_unsorted = (uint32_t*)calloc(Ra, 4); s->vals = (uint32_t*)calloc(Ra, 4);
+
+    /* ---- duplicateWithKeys, rasterizer_impl.cu:70-111 ---- */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (s->radii[idx] > 0) {
+            uint32_t off = (idx == 0) ? 0 : s->point_offsets[idx - 1];
+            uint32_t rminx, rminy, rmaxx, rmaxy;
+            getRect(s->means2D[2 * idx], s->means2D[2 * idx + 1], s->radii[idx], &rminx, &rminy, &rmaxx, &rmaxy, gx, gy);
+            uint32_t dbits; memcpy(&dbits, &s->depths[idx], 4);
+            for (uint32_t y = rminy; y < rmaxy; y++)
+                for (uint32_t x = rminx; x < rmaxx; x++) {
+                    uint64_t key = (uint64_t)(y * gx + x);
+                    key <<= 32; key |= dbits;
+                    s->keys_unsorted[off] = key; s->vals_unsorted[off] = (uint32_t)idx; off++;
+                }
+        }
+    }
+    /* ---- SortPairs on bits [0, 32+bit), rasterizer_impl.cu:304-312 ---- */
+    const int bit = (int)hsro_get_higher_msb(gx * gy);
+    stable_sort_pairs(s->keys_unsorted, s->vals_unsorted, s->keys, s->vals, (size_t)R, 32 + bit);
+
+    /* ---- memset + identifyTileRanges, rasterizer_impl.cu:314-322, :116-138 ---- */
+    for (int i = 0; i < R; i++) {
+        uint32_t cur = (uint32_t)(s->keys[i] >> 32);
+        if (i == 0) s->ranges[2 * cur] = 0;
+        else {
+            uint32_t prev = (uint32_t)(s->keys[i - 1] >> 32);
+            if (cur != prev) { s->ranges[2 * prev + 1] = (uint32_t)i; s->ranges[2 * cur] = (uint32_t)i; }
+        }
+        if (i == R - 1) s->ranges[2 * cur + 1] = (uint32_t)R;
+    }
+
+    /* ---- renderCUDA (forward.cu:261-398) / renderCUDA_SEM (forward.cu:400-538), one pixel per "thread" ---- */
+    const float* feat = colors_precomp ? colors_precomp : s->rgb;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long tile = 0; tile < (long)Tn; tile++) {
+        const uint32_t ty = (uint32_t)(tile / gx), tx = (uint32_t)(tile % gx);
+        const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        float* Sacc = (float*)malloc(sizeof(float) * (size_t)(K > 0 ? K : 1));
+        for (int tyy = 0; tyy < BLOCK_Y; tyy++)
+            for (int txx = 0; txx < BLOCK_X; txx++) {
+                uint32_t px = tx * BLOCK_X + txx, py = ty * BLOCK_Y + tyy;
+                if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
+                size_t pix_id = (size_t)W * py + px;
+                float pfx = (float)px, pfy = (float)py;
+                float T = 1.0f; uint32_t contributor = 0, last_contributor = 0;
+                float C[NUM_CHANNELS] = {0, 0, 0}; float Dd = 0; float median_D = 15.0f; float Mm = 0;
+                for (int ch = 0; ch < K; ch++) Sacc[ch] = 0;
+                for (uint32_t i = r0; i < r1; i++) {
+                    contributor++;
+                    uint32_t id = s->vals[i];
+                    float dx = s->means2D[2 * id] - pfx, dy = s->means2D[2 * id + 1] - pfy;
+                    const float* co = s->conic_opacity + 4 * (size_t)id;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    float alpha = fminf_(0.99f, co[3] * expf(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) break; /* done = true (forward.cu:358-362, :496-500) */
+                    for (int ch = 0; ch < NUM_CHANNELS; ch++) C[ch] += feat[(size_t)id * NUM_CHANNELS + ch] * alpha * T;
+                    Dd += s->depths[id] * alpha * T;
+                    if (s->semantic) { for (int ch = 0; ch < K; ch++) Sacc[ch] += semantics[(size_t)id * K + ch] * alpha * T; }
+                    else Mm += alpha * T;
+                    if (T > 0.5f && test_T < 0.5) median_D = s->depths[id]; /* forward.cu:371-376, :511-515 */
+                    T = test_T;
+                    last_contributor = contributor;
+                }
+                s->final_T[pix_id] = T; s->n_contrib[pix_id] = last_contributor;
+                for (int ch = 0; ch < NUM_CHANNELS; ch++) out_color[(size_t)ch * N + pix_id] = C[ch];
+                out_depth[pix_id] = Dd; out_median_depth[pix_id] = median_D; out_opacity[pix_id] = 1 - T;
+                if (s->semantic) { for (int ch = 0; ch < K; ch++) out_semantic[(size_t)ch * N + pix_id] = Sacc[ch]; }
+                else if (out_mask) out_mask[pix_id] = Mm;
+            }
+        free(Sacc);
+    }
+    return s;
+}
+
+/* backward.cu:20-139 */
+static void computeColorFromSH_bwd(int idx, int deg, int max_coeffs, const float* means, const float* campos, const float* shs,
+                                   const uint8_t* clamped, const float* dL_dcolor, float* dL_dmeans, float* dL_dshs)
+{
+    v3 pos = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
+    v3 dir_orig = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
+    float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    const float* sh = shs + (size_t)idx * max_coeffs * 3;
+    float* dsh = dL_dshs + (size_t)idx * max_coeffs * 3;
+    float dRGB[3];
+    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[3 * idx + c] * (clamped[3 * idx + c] ? 0.f : 1.f);
+    float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+#define SH(i) sh[(i) * 3 + c]
+#define DSH(i, v) for (int c = 0; c < 3; c++) dsh[(i) * 3 + c] = (v) * dRGB[c]
+    DSH(0, SH_C0);
+    if (deg > 0) {
+        DSH(1, -SH_C1 * y); DSH(2, SH_C1 * z); DSH(3, -SH_C1 * x);
+        for (int c = 0; c < 3; c++) { dRGBdx[c] = -SH_C1 * SH(3); dRGBdy[c] = -SH_C1 * SH(1); dRGBdz[c] = SH_C1 * SH(2); }
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            DSH(4, SH_C2[0] * xy); DSH(5, SH_C2[1] * yz); DSH(6, SH_C2[2] * (2.f * zz - xx - yy));
+            DSH(7, SH_C2[3] * xz); DSH(8, SH_C2[4] * (xx - yy));
+            for (int c = 0; c < 3; c++) {
+                dRGBdx[c] += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+                dRGBdy[c] += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+                dRGBdz[c] += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+            }
+            if (deg > 2) {
+                DSH(9, SH_C3[0] * y * (3.f * xx - yy)); DSH(10, SH_C3[1] * xy * z); DSH(11, SH_C3[2] * y * (4.f * zz - xx - yy));
+                DSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)); DSH(13, SH_C3[4] * x * (4.f * zz - xx - yy));
+                DSH(14, SH_C3[5] * z * (xx - yy)); DSH(15, SH_C3[6] * x * (xx - 3.f * yy));
+                for (int c = 0; c < 3; c++) {
+                    dRGBdx[c] += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
+                                  SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                                  SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy));
+                    dRGBdy[c] += (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
+                                  SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -3.f * 2.f * yz +
+                                  SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz + SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+                    dRGBdz[c] += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz +
+                                  SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13) * 4.f * 2.f * xz +
+                                  SH_C3[5] * SH(14) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SH
+#undef DSH
+    v3 dL_ddir = {dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2],
+                  dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2],
+                  dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2]};
+    v3 dm = dnormvdv3(dir_orig, dL_ddir);
+    dL_dmeans[3 * idx] += dm.x; dL_dmeans[3 * idx + 1] += dm.y; dL_dmeans[3 * idx + 2] += dm.z;
+}
+
+/*
+ * Backward.  Follows Rasterizer::backward (rasterizer_impl.cu:349-454) / backward_semantic
+ * (:614-731) according to how the state was produced.  Gradient outputs must be caller-allocated
+ * and are fully overwritten (the reference zero-fills them first, rasterize_points.cu:378-388).
+ * dL_dconic is [P,4] (only [0],[1],[3] written, backward.cu:658-660).  dL_dmean2D is [P,3].
+ * sem_alpha_mode 0 = reference-as-observed: the semantic->alpha term reads a scratch buffer the
+ * reference never writes (backward.cu:834, rasterizer_impl.cu:673-674), i.e. zeros.
+ */
+int hsro_backward(const HsroState* s, int D, int M, const float* background, const float* means3D, const float* shs,
+                  const float* colors_precomp, const float* semantics, const float* scales, float scale_modifier,
+                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                  const float* campos, float tan_fovx, float tan_fovy, const float* dL_dpix, const float* dL_dpix_sem,
+                  const float* dL_dpix_depth, const float* dL_dpix_median, const float* dL_dpix_opacity,
+                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantics,
+                  float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                  int sem_alpha_mode)
+{
+    (void)semantics;
+    if (sem_alpha_mode != 0) return -1;
+    const int P = s->P, W = s->W, H = s->H, K = s->semantic ? s->K : 0;
+    const size_t N = (size_t)W * H;
+    const uint32_t gx = (uint32_t)s->tiles_x, gy = (uint32_t)s->tiles_y;
+    const size_t Tn = (size_t)gx * gy;
+    const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);
+    const float* colors = colors_precomp ? colors_precomp : s->rgb;
+    const int NA = 10 + K; /* per-Gaussian accumulators: mean2D xy, conic xyw, opacity, colour rgb, depth, sem[K] */
+    size_t Pa = P ? (size_t)P : 1;
+    double* acc = (double*)calloc(Pa * (size_t)NA, sizeof(double));
+    if (!acc) return -2;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H); /* backward.cu:550-551, :759-760 */
+
+    /* ---- renderCUDA (backward.cu:472-666) / renderCUDA_SEM (backward.cu:669-899) ---- */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long tile = 0; tile < (long)Tn; tile++) {
+        const uint32_t ty = (uint32_t)(tile / gx), tx = (uint32_t)(tile % gx);
+        const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        float* dsem = (float*)malloc(sizeof(float) * (size_t)(K > 0 ? K : 1));
+        for (int tyy = 0; tyy < BLOCK_Y; tyy++)
+            for (int txx = 0; txx < BLOCK_X; txx++) {
+                uint32_t px = tx * BLOCK_X + txx, py = ty * BLOCK_Y + tyy;
+                if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
+                size_t pix_id = (size_t)W * py + px;
+                float pfx = (float)px, pfy = (float)py;
+                const float T_final = s->final_T[pix_id];
+                float T = T_final;
+                uint32_t contributor = r1 - r0;
+                const int last_contributor = (int)s->n_contrib[pix_id];
+                float accum_rec[NUM_CHANNELS] = {0, 0, 0}, dpx[NUM_CHANNELS], last_color[NUM_CHANNELS] = {0, 0, 0};
+                for (int c = 0; c < NUM_CHANNELS; c++) dpx[c] = dL_dpix[(size_t)c * N + pix_id];
+                const float dpd = dL_dpix_depth[pix_id], dpm = dL_dpix_median[pix_id], dpo = dL_dpix_opacity[pix_id];
+                for (int c = 0; c < K; c++) dsem[c] = dL_dpix_sem[(size_t)c * N + pix_id];
+                float accum_depth_rec = 0, accum_op_rec = 0, last_alpha = 0, last_depth = 0, last_op = 0;
+                for (uint32_t ii = r1; ii > r0; ii--) { /* back to front, backward.cu:562, :771 */
+                    contributor--;
+                    if ((int64_t)contributor >= (int64_t)last_contributor) continue;
+                    uint32_t id = s->vals[ii - 1];
+                    float dx = s->means2D[2 * id] - pfx, dy = s->means2D[2 * id + 1] - pfy;
+                    const float* co = s->conic_opacity + 4 * (size_t)id;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float G = expf(power);
+                    const float alpha = fminf_(0.99f, co[3] * G);
+                    if (alpha < 1.0f / 255.0f) continue;
+                    float test_T = T / (1.f - alpha);
+                    const float w = alpha * test_T;
+                    double* a = acc + (size_t)id * NA;
+                    float dL_dalpha = 0.0f;
+                    for (int ch = 0; ch < NUM_CHANNELS; ch++) {
+                        const float c = colors[(size_t)id * NUM_CHANNELS + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = c;
+                        dL_dalpha += (c - accum_rec[ch]) * dpx[ch];
+                        float v = w * dpx[ch];
+#pragma omp atomic
+                        a[6 + ch] += (double)v;
+                    }
+                    /* semantic: s == 0 (unwritten scratch), accum_rec_sem and last_semantic stay 0, so the
+                       dL_dalpha term (backward.cu:840) is exactly 0; only dL_dsemantics accumulates (:845) */
+                    for (int ch = 0; ch < K; ch++) {
+                        float v = w * dsem[ch];
+#pragma omp atomic
+                        a[10 + ch] += (double)v;
+                    }
+                    const float c_d = s->depths[id];
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    last_depth = c_d;
+                    dL_dalpha += (c_d - accum_depth_rec) * dpd;
+                    {
+                        float v = w * dpd;
+#pragma omp atomic
+                        a[9] += (double)v;
+                    }
+                    if (test_T > 0.5f && T < 0.5) { /* backward.cu:623-626, :854-857 */
+#pragma omp atomic
+                        a[9] += (double)dpm;
+                    }
+                    accum_op_rec = last_alpha * last_op + (1.f - last_alpha) * accum_op_rec;
+                    last_op = 1.f;
+                    dL_dalpha += (1.f - accum_op_rec) * dpo;
+                    {
+                        float v = w * dpo;
+#pragma omp atomic
+                        a[5] += (double)v;
+                    }
+                    dL_dalpha *= test_T;
+                    T = test_T;
+                    last_alpha = alpha;
+                    float bg_dot = 0;
+                    for (int i = 0; i < NUM_CHANNELS; i++) bg_dot += background[i] * dpx[i];
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    const float dL_dG = co[3] * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                    const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                    float v0 = dL_dG * dG_ddelx * ddelx_dx, v1 = dL_dG * dG_ddely * ddely_dy;
+                    float v2 = -0.5f * gdx * dx * dL_dG, v3_ = -0.5f * gdx * dy * dL_dG, v4_ = -0.5f * gdy * dy * dL_dG;
+                    float v5 = G * dL_dalpha;
+#pragma omp atomic
+                    a[0] += (double)v0;
+#pragma omp atomic
+                    a[1] += (double)v1;
+#pragma omp atomic
+                    a[2] += (double)v2;
+#pragma omp atomic
+                    a[3] += (double)v3_;
+#pragma omp atomic
+                    a[4] += (double)v4_;
+#pragma omp atomic
+                    a[5] += (double)v5;
+                }
+            }
+        free(dsem);
+    }
+    for (int i = 0; i < P; i++) {
+        const double* a = acc + (size_t)i * NA;
+        dL_dmean2D[3 * i] = (float)a[0]; dL_dmean2D[3 * i + 1] = (float)a[1]; dL_dmean2D[3 * i + 2] = 0.f;
+        dL_dconic[4 * i] = (float)a[2]; dL_dconic[4 * i + 1] = (float)a[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = (float)a[4];
+        dL_dopacity[i] = (float)a[5];
+        for (int c = 0; c < 3; c++) dL_dcolor[3 * i + c] = (float)a[6 + c];
+        dL_ddepth[i] = (float)a[9];
+        for (int c = 0; c < K; c++) dL_dsemantics[(size_t)i * K + c] = (float)a[10 + c];
+    }
+    free(acc);
+
+    memset(dL_dmean3D, 0, sizeof(float) * 3 * (size_t)P);
+    memset(dL_dcov3D, 0, sizeof(float) * 6 * (size_t)P);
+    if (dL_dscale) memset(dL_dscale, 0, sizeof(float) * 3 * (size_t)P);
+    if (dL_drot) memset(dL_drot, 0, sizeof(float) * 4 * (size_t)P);
+    if (dL_dsh && M > 0) memset(dL_dsh, 0, sizeof(float) * 3 * (size_t)M * (size_t)P);
+    const float* cov3Ds = cov3D_precomp ? cov3D_precomp : s->cov3D;
+
+    /* ---- computeCov2DCUDA, backward.cu:144-274 ---- */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (!(s->radii[idx] > 0)) continue;
+        const float* cov3D = cov3Ds + 6 * (size_t)idx;
+        v3 mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        const float dcx = dL_dconic[4 * idx], dcy = dL_dconic[4 * idx + 1], dcz = dL_dconic[4 * idx + 3];
+        v3 t; float txtz, tytz; m3 T, Vrk, c2;
+        cov2d_core(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &t, &txtz, &tytz, &T, &Vrk, &c2);
+        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        float a = c2.c[0][0] + 0.3f, b = c2.c[0][1], c = c2.c[1][1] + 0.3f;
+        float denom = a * c - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float* dcov = dL_dcov3D + 6 * (size_t)idx;
+#define TT(i, j) T.c[i][j]
+#define VV(i, j) Vrk.c[i][j]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
+            dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
+            dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+            dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+            dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+            dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+            dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+            dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+            dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+        } else {
+            for (int i = 0; i < 6; i++) dcov[i] = 0;
+        }
+        float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
+                        (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+        float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
+                        (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+        float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
+                        (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+        float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
+                        (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+        float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
+                        (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+        float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
+                        (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+#undef TT
+#undef VV
+        /* W as built at backward.cu:182-185: W[c][r] */
+        const float* vm = viewmatrix;
+        m3 Wm = m3_make(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+        float dL_dJ00 = Wm.c[0][0] * dL_dT00 + Wm.c[0][1] * dL_dT01 + Wm.c[0][2] * dL_dT02;
+        float dL_dJ02 = Wm.c[2][0] * dL_dT00 + Wm.c[2][1] * dL_dT01 + Wm.c[2][2] * dL_dT02;
+        float dL_dJ11 = Wm.c[1][0] * dL_dT10 + Wm.c[1][1] * dL_dT11 + Wm.c[1][2] * dL_dT12;
+        float dL_dJ12 = Wm.c[2][0] * dL_dT10 + Wm.c[2][1] * dL_dT11 + Wm.c[2][2] * dL_dT12;
+        float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float h_x = focal_x, h_y = focal_y;
+        float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+        v3 dt = {dL_dtx, dL_dty, dL_dtz};
+        v3 dm = transformVec4x3Transpose(dt, viewmatrix);
+        dL_dmean3D[3 * idx] = dm.x; dL_dmean3D[3 * idx + 1] = dm.y; dL_dmean3D[3 * idx + 2] = dm.z; /* assignment, :273 */
+    }
+
+    /* ---- preprocessCUDA (backward), backward.cu:346-412 (also the semantic path, :1117) ---- */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (!(s->radii[idx] > 0)) continue;
+        v3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        const float* proj = projmatrix; const float* view = viewmatrix;
+        v4 m_hom = transformPoint4x4(m, proj);
+        float m_w = 1.0f / (m_hom.w + 0.0000001f);
+        float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+        float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+        const float d2x = dL_dmean2D[3 * idx], d2y = dL_dmean2D[3 * idx + 1];
+        float gxm = (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
+        float gym = (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
+        float gzm = (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
+        dL_dmean3D[3 * idx] += gxm; dL_dmean3D[3 * idx + 1] += gym; dL_dmean3D[3 * idx + 2] += gzm;
+        float mul3 = view[2] * m.x + view[6] * m.y + view[10] * m.z + view[14];
+        const float dd = dL_ddepth[idx];
+        dL_dmean3D[3 * idx] += (view[2] - view[3] * mul3) * dd;
+        dL_dmean3D[3 * idx + 1] += (view[6] - view[7] * mul3) * dd;
+        dL_dmean3D[3 * idx + 2] += (view[10] - view[11] * mul3) * dd;
+        if (shs) computeColorFromSH_bwd(idx, D, M, means3D, campos, shs, s->clamped, dL_dcolor, dL_dmean3D, dL_dsh);
+        if (scales) {
+            /* computeCov3D backward, backward.cu:278-341 */
+            float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
+            m3 Rm = m3_make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                            2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                            2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+            m3 S = m3_make(1, 0, 0, 0, 1, 0, 0, 0, 1);
+            float sx = scale_modifier * scales[3 * idx], sy = scale_modifier * scales[3 * idx + 1], sz = scale_modifier * scales[3 * idx + 2];
+            S.c[0][0] = sx; S.c[1][1] = sy; S.c[2][2] = sz;
+            m3 Mm = m3_mul(&S, &Rm);
+            const float* dc = dL_dcov3D + 6 * (size_t)idx;
+            m3 dSig = m3_make(dc[0], 0.5f * dc[1], 0.5f * dc[2], 0.5f * dc[1], dc[3], 0.5f * dc[4], 0.5f * dc[2], 0.5f * dc[4], dc[5]);
+            m3 M2 = Mm;
+            for (int cc = 0; cc < 3; cc++) for (int rr = 0; rr < 3; rr++) M2.c[cc][rr] = 2.0f * Mm.c[cc][rr]; /* 2.0f * M */
+            m3 dL_dM = m3_mul(&M2, &dSig);
+            m3 Rt = m3_transpose(&Rm);
+            m3 dMt = m3_transpose(&dL_dM);
+            dL_dscale[3 * idx] = Rt.c[0][0] * dMt.c[0][0] + Rt.c[0][1] * dMt.c[0][1] + Rt.c[0][2] * dMt.c[0][2];
+            dL_dscale[3 * idx + 1] = Rt.c[1][0] * dMt.c[1][0] + Rt.c[1][1] * dMt.c[1][1] + Rt.c[1][2] * dMt.c[1][2];
+            dL_dscale[3 * idx + 2] = Rt.c[2][0] * dMt.c[2][0] + Rt.c[2][1] * dMt.c[2][1] + Rt.c[2][2] * dMt.c[2][2];
+            for (int k = 0; k < 3; k++) { dMt.c[0][k] *= sx; dMt.c[1][k] *= sy; dMt.c[2][k] *= sz; }
+#define DM(i, j) dMt.c[i][j]
+            float qx = 2 * z * (DM(0, 1) - DM(1, 0)) + 2 * y * (DM(2, 0) - DM(0, 2)) + 2 * x * (DM(1, 2) - DM(2, 1));
+            float qy = 2 * y * (DM(1, 0) + DM(0, 1)) + 2 * z * (DM(2, 0) + DM(0, 2)) + 2 * r * (DM(1, 2) - DM(2, 1)) - 4 * x * (DM(2, 2) + DM(1, 1));
+            float qz = 2 * x * (DM(1, 0) + DM(0, 1)) + 2 * r * (DM(2, 0) - DM(0, 2)) + 2 * z * (DM(1, 2) + DM(2, 1)) - 4 * y * (DM(2, 2) + DM(0, 0));
+            float qw = 2 * r * (DM(0, 1) - DM(1, 0)) + 2 * x * (DM(2, 0) + DM(0, 2)) + 2 * y * (DM(1, 2) + DM(2, 1)) - 4 * z * (DM(1, 1) + DM(0, 0));
+#undef DM
+            dL_drot[4 * idx] = qx; dL_drot[4 * idx + 1] = qy; dL_drot[4 * idx + 2] = qz; dL_drot[4 * idx + 3] = qw;
+        }
+    }
+    return 0;
+}
+
+void hsro_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int hsro_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
