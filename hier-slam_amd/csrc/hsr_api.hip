@@ -1,0 +1,481 @@
+// hsr_api.hip — the C ABI of libhsr_rast.so (see include/hsr_rasterizer.h): argument validation,
+// state-buffer carving and stage orchestration.  Host code only; kernels live in the other units.
+//
+// Stage order of one forward (reference Rasterizer::forward[_semantic], rasterizer_impl.cu:198-345,
+// :460-610):   preprocess (+ per-block tile-count sums) -> scan of the block sums -> 4-byte D2H of
+// num_rendered (the reference's blocking cudaMemcpy, rasterizer_impl.cu:285/:548; it sizes the
+// binning buffer) -> key emission (finishes the scan in-block) -> radix sort -> tile ranges -> tile
+// render.  One backward: zero the atomically-accumulated sums -> tile backward -> fused per-Gaussian
+// backward.  The library holds no state between calls; the reference's per-call cudaMalloc/cudaFree
+// scratch in backward_semantic (rasterizer_impl.cu:673-701) has no counterpart.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hsr_rasterizer.h"
+#include "hsr_common.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+template <typename T>
+inline void take(char*& p, T*& out, size_t count)
+{
+    uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255;
+    out = reinterpret_cast<T*>(a);
+    p = reinterpret_cast<char*>(out + count);
+}
+
+uint32_t higher_msb(uint32_t n)  // reference getHigherMsb, rasterizer_impl.cu:35-50
+{
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+int acquire(hsr_buffer* b, size_t need, const char* what, char** out)
+{
+    if (!b) {
+        hsr_set_error("%s buffer descriptor is NULL", what);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!(b->ptr && b->capacity >= need)) {
+        if (!b->grow) {
+            hsr_set_error("%s buffer too small: %zu bytes needed, %zu available, no grow callback", what, need, b->capacity);
+            return HSR_ERR_BUFFER_TOO_SMALL;
+        }
+        char* p = b->grow(need, b->user);
+        if (!p) {
+            hsr_set_error("%s buffer grow callback failed for %zu bytes", what, need);
+            return HSR_ERR_BUFFER_TOO_SMALL;
+        }
+        b->ptr = p;
+        b->capacity = need;
+    }
+    *out = b->ptr;
+    return HSR_OK;
+}
+
+thread_local uint32_t* g_pinned = nullptr;
+
+int read_counter(const uint32_t* dev, uint32_t* host_out, hipStream_t stream)
+{
+    if (!g_pinned) HSR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_pinned), 64, hipHostMallocDefault));
+    HSR_HIP_CHECK(hipMemcpyAsync(g_pinned, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HSR_HIP_CHECK(hipStreamSynchronize(stream));
+    *host_out = g_pinned[0];
+    return HSR_OK;
+}
+
+struct FwdIn {
+    int P, D, M, K, semantic, W, H, prefiltered, debug;
+    const float *background, *means3D, *shs, *colors_precomp, *semantics, *opacities, *scales, *rotations, *cov3D_precomp,
+        *viewmatrix, *projmatrix, *cam_pos;
+    float scale_modifier, tan_fovx, tan_fovy;
+    float *out_color, *out_semantic, *out_depth, *out_median, *out_opacity, *out_mask;
+    int* radii;
+};
+
+int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, const FwdIn& in, hipStream_t stream)
+{
+    const int P = in.P, W = in.W, H = in.H;
+    if (P < 0 || W <= 0 || H <= 0) {
+        hsr_set_error("invalid sizes P=%d W=%d H=%d", P, W, H);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!in.out_color || !in.out_depth || !in.out_median || !in.out_opacity || (in.semantic && in.K > 0 && !in.out_semantic)) {
+        hsr_set_error("an output image pointer is NULL");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (in.semantic && in.K < 0) {
+        hsr_set_error("K must be >= 0");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    const size_t N = (size_t)W * H;
+    if (P == 0) {
+        // reference: P == 0 short-circuits with zero-filled outputs and rendered = 0 (rasterize_points.cu:294-295)
+        HSR_HIP_CHECK(hipMemsetAsync(in.out_color, 0, sizeof(float) * 3 * N, stream));
+        HSR_HIP_CHECK(hipMemsetAsync(in.out_depth, 0, sizeof(float) * N, stream));
+        HSR_HIP_CHECK(hipMemsetAsync(in.out_median, 0, sizeof(float) * N, stream));
+        HSR_HIP_CHECK(hipMemsetAsync(in.out_opacity, 0, sizeof(float) * N, stream));
+        if (in.out_mask) HSR_HIP_CHECK(hipMemsetAsync(in.out_mask, 0, sizeof(float) * N, stream));
+        if (in.semantic && in.K > 0) HSR_HIP_CHECK(hipMemsetAsync(in.out_semantic, 0, sizeof(float) * in.K * N, stream));
+        return 0;
+    }
+    if (!in.means3D || !in.opacities || !in.viewmatrix || !in.projmatrix) {
+        hsr_set_error("means3D, opacities, viewmatrix and projmatrix are required");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!in.colors_precomp && !(in.shs && in.cam_pos && in.M > 0)) {
+        hsr_set_error("provide colors_precomp, or shs with M > 0 and cam_pos");  // rasterizer_impl.cu:246-249
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!in.cov3D_precomp && !(in.scales && in.rotations)) {
+        hsr_set_error("provide cov3D_precomp, or scales and rotations");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (in.semantic && in.K > 0 && !in.semantics) {
+        hsr_set_error("semantics_precomp is NULL but K=%d", in.K);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (in.shs && !in.colors_precomp && (in.D < 0 || in.D > 3 || in.M < (in.D + 1) * (in.D + 1))) {
+        hsr_set_error("SH degree %d needs M >= %d coefficients (got %d)", in.D, (in.D + 1) * (in.D + 1), in.M);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+
+    int rc;
+    char* gptr;
+    char* iptr;
+    if ((rc = acquire(geometry, hsr_required_geometry_bytes(P), "geometry", &gptr)) != HSR_OK) return rc;
+    if ((rc = acquire(image, hsr_required_image_bytes(W, H), "image", &iptr)) != HSR_OK) return rc;
+    GeomState g;
+    ImgState im;
+    hsr_carve_geom(gptr, P, &g);
+    hsr_carve_img(iptr, W, H, &im);
+
+    const int tiles_x = (W + HSR_TILE_X - 1) / HSR_TILE_X, tiles_y = (H + HSR_TILE_Y - 1) / HSR_TILE_Y;
+    const int T = tiles_x * tiles_y;
+    int* radii = in.radii ? in.radii : g.radii;
+
+    PreprocessArgs pa;
+    pa.P = P; pa.D = in.D; pa.M = in.M; pa.W = W; pa.H = H;
+    pa.means3D = in.means3D; pa.scales = in.scales; pa.scale_modifier = in.scale_modifier; pa.rotations = in.rotations;
+    pa.opacities = in.opacities; pa.shs = in.shs; pa.cov3D_precomp = in.cov3D_precomp; pa.colors_precomp = in.colors_precomp;
+    pa.viewmatrix = in.viewmatrix; pa.projmatrix = in.projmatrix; pa.cam_pos = in.cam_pos;
+    pa.tan_fovx = in.tan_fovx; pa.tan_fovy = in.tan_fovy;
+    pa.focal_y = H / (2.0f * in.tan_fovy);  // rasterizer_impl.cu:226-227
+    pa.focal_x = W / (2.0f * in.tan_fovx);
+    pa.radii = radii; pa.prefiltered = in.prefiltered; pa.tiles_x = tiles_x; pa.tiles_y = tiles_y;
+
+    hsr_launch_preprocess(pa, g, stream);
+    HSR_LAUNCH_CHECK(in.debug, stream);
+    hsr_launch_scan_block_sums(P, g, stream);
+    HSR_LAUNCH_CHECK(in.debug, stream);
+
+    uint32_t R32 = 0;
+    if ((rc = read_counter(g.counters, &R32, stream)) != HSR_OK) return rc;
+    if (R32 > 0x7fffffffu) {
+        hsr_set_error("num_rendered %u overflows int", R32);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    const int R = (int)R32;
+
+    char* bptr;
+    if ((rc = acquire(binning, hsr_required_binning_bytes(R), "binning", &bptr)) != HSR_OK) return rc;
+    BinState b;
+    hsr_carve_bin(bptr, R, &b);
+
+    const int end_bit = 32 + (int)higher_msb((uint32_t)T);  // rasterizer_impl.cu:304-312
+    const int passes = (end_bit + 7) / 8;
+    // emit into the buffer pair from which `passes` ping-pong steps end in (keys, vals)
+    uint64_t* emit_k = (passes & 1) ? b.keys_unsorted : b.keys;
+    uint32_t* emit_v = (passes & 1) ? b.vals_unsorted : b.vals;
+    {
+        BinState be = b;
+        be.keys_unsorted = emit_k;
+        be.vals_unsorted = emit_v;
+        hsr_launch_duplicate(P, radii, tiles_x, tiles_y, g, be, stream);
+    }
+    HSR_LAUNCH_CHECK(in.debug, stream);
+    if ((rc = hsr_launch_sort_pairs(b, R, end_bit, stream)) != HSR_OK) return rc;
+    HSR_LAUNCH_CHECK(in.debug, stream);
+    if ((rc = hsr_launch_tile_ranges(R, T, b.keys, im.ranges, stream)) != HSR_OK) return rc;
+    HSR_LAUNCH_CHECK(in.debug, stream);
+
+    RenderFwdArgs ra;
+    ra.W = W; ra.H = H; ra.K = in.semantic ? in.K : 0; ra.semantic = in.semantic;
+    ra.ranges = im.ranges; ra.point_list = b.vals; ra.means2D = g.means2D; ra.conic_opacity = g.conic_opacity;
+    ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb; ra.semantics = in.semantics;
+    ra.final_T = im.final_T; ra.n_contrib = im.n_contrib;
+    ra.out_color = in.out_color; ra.out_semantic = in.out_semantic; ra.out_depth = in.out_depth;
+    ra.out_median_depth = in.out_median; ra.out_opacity = in.out_opacity; ra.out_mask = in.out_mask;
+    if (!in.semantic && !in.out_mask) {
+        hsr_set_error("out_mask is NULL");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    hsr_launch_render_forward(ra, stream);
+    HSR_LAUNCH_CHECK(in.debug, stream);
+    return R;
+}
+
+struct BwdIn {
+    int P, D, M, K, semantic, R, W, H, debug;
+    const float *background, *means3D, *shs, *colors_precomp, *semantics, *scales, *rotations, *cov3D_precomp, *viewmatrix,
+        *projmatrix, *campos;
+    float scale_modifier, tan_fovx, tan_fovy;
+    const int* radii;
+    const char *geom, *binning, *img;
+    const float *dL_dpix, *dL_dpix_sem, *dL_dpix_depth, *dL_dpix_median, *dL_dpix_opacity;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dsemantics, *dL_ddepth, *dL_dmean3D, *dL_dcov3D, *dL_dsh,
+        *dL_dscale, *dL_drot;
+};
+
+int backward_impl(const BwdIn& in, hipStream_t stream)
+{
+    const int P = in.P, W = in.W, H = in.H;
+    if (P < 0 || W <= 0 || H <= 0 || in.R < 0) {
+        hsr_set_error("invalid sizes P=%d W=%d H=%d R=%d", P, W, H, in.R);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (P == 0) return HSR_OK;
+    if (!in.geom || !in.img || (in.R > 0 && !in.binning)) {
+        hsr_set_error("state buffers from the forward call are required");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!in.dL_dpix || !in.dL_dpix_depth || !in.dL_dpix_median || !in.dL_dpix_opacity ||
+        (in.semantic && in.K > 0 && (!in.dL_dpix_sem || !in.dL_dsemantics))) {
+        hsr_set_error("an upstream-gradient pointer is NULL");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!in.dL_dmean2D || !in.dL_dconic || !in.dL_dopacity || !in.dL_dcolor || !in.dL_ddepth || !in.dL_dmean3D || !in.dL_dcov3D) {
+        hsr_set_error("a gradient output pointer is NULL");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (in.scales && (!in.rotations || !in.dL_dscale || !in.dL_drot)) {
+        hsr_set_error("scales given without rotations / dL_dscale / dL_drot");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!in.background) {
+        hsr_set_error("background is NULL");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    GeomState g;
+    ImgState im;
+    BinState b;
+    hsr_carve_geom(const_cast<char*>(in.geom), P, &g);
+    hsr_carve_img(const_cast<char*>(in.img), W, H, &im);
+    hsr_carve_bin(const_cast<char*>(in.binning), in.R, &b);
+    const int* radii = in.radii ? in.radii : g.radii;
+    const int K = in.semantic ? in.K : 0;
+
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dmean2D, 0, sizeof(float) * 3 * (size_t)P, stream));
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dconic, 0, sizeof(float) * 4 * (size_t)P, stream));
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dopacity, 0, sizeof(float) * (size_t)P, stream));
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dcolor, 0, sizeof(float) * 3 * (size_t)P, stream));
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_ddepth, 0, sizeof(float) * (size_t)P, stream));
+    if (K > 0) HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsemantics, 0, sizeof(float) * (size_t)K * (size_t)P, stream));
+    // SH coefficients above the active degree (and those of culled Gaussians) receive no gradient
+    if (!in.colors_precomp && in.shs && in.dL_dsh && in.M > 0)
+        HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsh, 0, sizeof(float) * 3 * (size_t)in.M * (size_t)P, stream));
+
+    if (in.R > 0) {
+        RenderBwdArgs ra;
+        ra.W = W; ra.H = H; ra.K = K; ra.semantic = in.semantic; ra.P = P;
+        ra.bg = in.background; ra.ranges = im.ranges; ra.point_list = b.vals; ra.means2D = g.means2D;
+        ra.conic_opacity = g.conic_opacity; ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb;
+        ra.final_T = im.final_T; ra.n_contrib = im.n_contrib;
+        ra.dL_dpix = in.dL_dpix; ra.dL_dpix_sem = in.dL_dpix_sem; ra.dL_dpix_depth = in.dL_dpix_depth;
+        ra.dL_dpix_median = in.dL_dpix_median; ra.dL_dpix_opacity = in.dL_dpix_opacity;
+        ra.dL_dmean2D = in.dL_dmean2D; ra.dL_dconic = in.dL_dconic; ra.dL_dopacity = in.dL_dopacity;
+        ra.dL_dcolor = in.dL_dcolor; ra.dL_dsemantics = in.dL_dsemantics; ra.dL_ddepth = in.dL_ddepth;
+        hsr_launch_render_backward(ra, stream);
+        HSR_LAUNCH_CHECK(in.debug, stream);
+    }
+
+    PreBwdArgs pb;
+    pb.P = P; pb.D = in.D; pb.M = in.M; pb.means3D = in.means3D; pb.radii = radii;
+    pb.shs = in.colors_precomp ? nullptr : in.shs; pb.clamped = g.clamped; pb.scales = in.scales; pb.rotations = in.rotations;
+    pb.scale_modifier = in.scale_modifier; pb.cov3Ds = in.cov3D_precomp ? in.cov3D_precomp : g.cov3D;
+    pb.viewmatrix = in.viewmatrix; pb.projmatrix = in.projmatrix;
+    pb.focal_y = H / (2.0f * in.tan_fovy); pb.focal_x = W / (2.0f * in.tan_fovx);
+    pb.tan_fovx = in.tan_fovx; pb.tan_fovy = in.tan_fovy; pb.campos = in.campos;
+    pb.dL_dmean2D = in.dL_dmean2D; pb.dL_dconic = in.dL_dconic; pb.dL_dmean3D = in.dL_dmean3D; pb.dL_dcolor = in.dL_dcolor;
+    pb.dL_ddepth = in.dL_ddepth; pb.dL_dcov3D = in.dL_dcov3D; pb.dL_dsh = in.dL_dsh; pb.dL_dscale = in.dL_dscale;
+    pb.dL_drot = in.dL_drot;
+    if (pb.shs && (!in.dL_dsh || !in.campos)) {
+        hsr_set_error("shs given without dL_dsh / campos");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    hsr_launch_preprocess_backward(pb, stream);
+    HSR_LAUNCH_CHECK(in.debug, stream);
+    return HSR_OK;
+}
+
+}  // namespace
+
+void hsr_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+size_t hsr_carve_geom(char* base, int P, GeomState* out)
+{
+    char* p = base;
+    GeomState g;
+    const size_t Pn = (size_t)(P > 0 ? P : 1);
+    take(p, g.depths, Pn);
+    take(p, g.means2D, Pn);
+    take(p, g.conic_opacity, Pn);
+    take(p, g.cov3D, Pn * 6);
+    take(p, g.rgb, Pn * 3);
+    take(p, g.clamped, Pn * 3);
+    take(p, g.tiles_touched, Pn);
+    take(p, g.point_offsets, Pn);
+    take(p, g.radii, Pn);
+    take(p, g.block_sums, (Pn + 255) / 256 + 1);
+    take(p, g.counters, 8);
+    if (out) *out = g;
+    return (size_t)(p - base);
+}
+size_t hsr_carve_img(char* base, int W, int H, ImgState* out)
+{
+    char* p = base;
+    ImgState s;
+    const size_t N = (size_t)W * H;
+    const size_t T = (size_t)((W + HSR_TILE_X - 1) / HSR_TILE_X) * ((H + HSR_TILE_Y - 1) / HSR_TILE_Y);
+    take(p, s.ranges, T);
+    take(p, s.final_T, N);
+    take(p, s.n_contrib, N);
+    if (out) *out = s;
+    return (size_t)(p - base);
+}
+size_t hsr_carve_bin(char* base, int R, BinState* out)
+{
+    char* p = base;
+    BinState b;
+    const size_t Rn = (size_t)(R > 0 ? R : 1);
+    take(p, b.keys_unsorted, Rn);
+    take(p, b.keys, Rn);
+    take(p, b.vals_unsorted, Rn);
+    take(p, b.vals, Rn);
+    take(p, b.hist, hsr_sort_hist_entries(R));
+    if (out) *out = b;
+    return (size_t)(p - base);
+}
+
+extern "C" {
+
+size_t hsr_required_geometry_bytes(int P) { return hsr_carve_geom(nullptr, P, nullptr) + 256; }
+size_t hsr_required_image_bytes(int width, int height) { return hsr_carve_img(nullptr, width, height, nullptr) + 256; }
+size_t hsr_required_binning_bytes(int num_rendered) { return hsr_carve_bin(nullptr, num_rendered, nullptr) + 256; }
+
+const char* hsr_last_error(void) { return g_err; }
+const char* hsr_version(void) { return "hsr_rast 0.1 gfx950"; }
+
+int hsr_get_state_layout(int P, int width, int height, int num_rendered, hsr_state_layout* out)
+{
+    if (!out) return HSR_ERR_INVALID_ARGUMENT;
+    GeomState g;
+    ImgState im;
+    BinState b;
+    hsr_carve_geom(nullptr, P, &g);
+    hsr_carve_img(nullptr, width, height, &im);
+    hsr_carve_bin(nullptr, num_rendered, &b);
+#define OFF(p) ((size_t) reinterpret_cast<uintptr_t>(p))
+    out->geom_depths = OFF(g.depths); out->geom_means2D = OFF(g.means2D); out->geom_conic_opacity = OFF(g.conic_opacity);
+    out->geom_cov3D = OFF(g.cov3D); out->geom_rgb = OFF(g.rgb); out->geom_clamped = OFF(g.clamped);
+    out->geom_tiles_touched = OFF(g.tiles_touched); out->geom_point_offsets = OFF(g.point_offsets); out->geom_radii = OFF(g.radii);
+    out->bin_keys_unsorted = OFF(b.keys_unsorted); out->bin_keys = OFF(b.keys); out->bin_vals_unsorted = OFF(b.vals_unsorted);
+    out->bin_vals = OFF(b.vals);
+    out->img_ranges = OFF(im.ranges); out->img_final_T = OFF(im.final_T); out->img_n_contrib = OFF(im.n_contrib);
+#undef OFF
+    return HSR_OK;
+}
+
+int hsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream)
+{
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) {
+        hsr_set_error("hsr_mark_visible: invalid arguments");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    hsr_launch_mark_visible(P, means3D, viewmatrix, projmatrix, present, static_cast<hipStream_t>(stream));
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+int hsr_forward(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, int P, int D, int M, const float* background,
+                int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_median_depth,
+                float* out_opacity, float* out_mask, int* radii, int debug, void* stream)
+{
+    FwdIn in;
+    in.P = P; in.D = D; in.M = M; in.K = 0; in.semantic = 0; in.W = width; in.H = height; in.prefiltered = prefiltered; in.debug = debug;
+    in.background = background; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.semantics = nullptr;
+    in.opacities = opacities; in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp;
+    in.viewmatrix = viewmatrix; in.projmatrix = projmatrix; in.cam_pos = cam_pos;
+    in.scale_modifier = scale_modifier; in.tan_fovx = tan_fovx; in.tan_fovy = tan_fovy;
+    in.out_color = out_color; in.out_semantic = nullptr; in.out_depth = out_depth; in.out_median = out_median_depth;
+    in.out_opacity = out_opacity; in.out_mask = out_mask; in.radii = radii;
+    return forward_impl(geometry, binning, image, in, static_cast<hipStream_t>(stream));
+}
+
+int hsr_forward_semantic(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, int P, int D, int M, int K,
+                         const float* background, int width, int height, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* semantics_precomp, const float* opacities,
+                         const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                         float tan_fovy, int prefiltered, float* out_color, float* out_semantic, float* out_depth,
+                         float* out_median_depth, float* out_opacity, int* radii, int debug, void* stream)
+{
+    FwdIn in;
+    in.P = P; in.D = D; in.M = M; in.K = K; in.semantic = 1; in.W = width; in.H = height; in.prefiltered = prefiltered; in.debug = debug;
+    in.background = background; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.semantics = semantics_precomp;
+    in.opacities = opacities; in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp;
+    in.viewmatrix = viewmatrix; in.projmatrix = projmatrix; in.cam_pos = cam_pos;
+    in.scale_modifier = scale_modifier; in.tan_fovx = tan_fovx; in.tan_fovy = tan_fovy;
+    in.out_color = out_color; in.out_semantic = out_semantic; in.out_depth = out_depth; in.out_median = out_median_depth;
+    in.out_opacity = out_opacity; in.out_mask = nullptr; in.radii = radii;
+    return forward_impl(geometry, binning, image, in, static_cast<hipStream_t>(stream));
+}
+
+int hsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, const char* geom_buffer,
+                 const char* binning_buffer, const char* img_buffer, const float* dL_dpix, const float* dL_dpix_depth,
+                 const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity, float* dL_dmean2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    BwdIn in;
+    in.P = P; in.D = D; in.M = M; in.K = 0; in.semantic = 0; in.R = R; in.W = width; in.H = height; in.debug = debug;
+    in.background = background; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.semantics = nullptr;
+    in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.viewmatrix = viewmatrix;
+    in.projmatrix = projmatrix; in.campos = campos; in.scale_modifier = scale_modifier; in.tan_fovx = tan_fovx; in.tan_fovy = tan_fovy;
+    in.radii = radii; in.geom = geom_buffer; in.binning = binning_buffer; in.img = img_buffer;
+    in.dL_dpix = dL_dpix; in.dL_dpix_sem = nullptr; in.dL_dpix_depth = dL_dpix_depth; in.dL_dpix_median = dL_dpix_median_depth;
+    in.dL_dpix_opacity = dL_dpix_final_opacity;
+    in.dL_dmean2D = dL_dmean2D; in.dL_dconic = dL_dconic; in.dL_dopacity = dL_dopacity; in.dL_dcolor = dL_dcolor;
+    in.dL_dsemantics = nullptr; in.dL_ddepth = dL_ddepth; in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = dL_dcov3D; in.dL_dsh = dL_dsh;
+    in.dL_dscale = dL_dscale; in.dL_drot = dL_drot;
+    return backward_impl(in, static_cast<hipStream_t>(stream));
+}
+
+int hsr_backward_semantic(int P, int D, int M, int K, int R, const float* background, int width, int height,
+                          const float* means3D, const float* shs, const float* colors_precomp, const float* semantics_precomp,
+                          const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                          const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                          const int* radii, const char* geom_buffer, const char* binning_buffer, const char* img_buffer,
+                          const float* dL_dpix, const float* dL_dpix_semantic, const float* dL_dpix_depth,
+                          const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity, float* dL_dmean2D,
+                          float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantics, float* dL_ddepth,
+                          float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                          void* stream)
+{
+    BwdIn in;
+    in.P = P; in.D = D; in.M = M; in.K = K; in.semantic = 1; in.R = R; in.W = width; in.H = height; in.debug = debug;
+    in.background = background; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.semantics = semantics_precomp;
+    in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.viewmatrix = viewmatrix;
+    in.projmatrix = projmatrix; in.campos = campos; in.scale_modifier = scale_modifier; in.tan_fovx = tan_fovx; in.tan_fovy = tan_fovy;
+    in.radii = radii; in.geom = geom_buffer; in.binning = binning_buffer; in.img = img_buffer;
+    in.dL_dpix = dL_dpix; in.dL_dpix_sem = dL_dpix_semantic; in.dL_dpix_depth = dL_dpix_depth; in.dL_dpix_median = dL_dpix_median_depth;
+    in.dL_dpix_opacity = dL_dpix_final_opacity;
+    in.dL_dmean2D = dL_dmean2D; in.dL_dconic = dL_dconic; in.dL_dopacity = dL_dopacity; in.dL_dcolor = dL_dcolor;
+    in.dL_dsemantics = dL_dsemantics; in.dL_ddepth = dL_ddepth; in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = dL_dcov3D; in.dL_dsh = dL_dsh;
+    in.dL_dscale = dL_dscale; in.dL_drot = dL_drot;
+    return backward_impl(in, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

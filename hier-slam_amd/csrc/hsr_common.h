@@ -1,0 +1,172 @@
+// hsr_common.h — shared declarations of the gfx950 rasterizer library (internal, not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define HSR_TILE_X 16
+#define HSR_TILE_Y 16
+#define HSR_TILE_PIX 256
+#define HSR_NUM_CHANNELS 3
+
+// ---- opaque state, carved out of the caller's three byte buffers (all fields 256-B aligned) ----
+// The reference keeps the same information in GeometryState / ImageState / BinningState
+// (cuda_rasterizer/rasterizer_impl.h:29-64); the layout here is ours: ranges are per TILE (the
+// reference reserves one per pixel, rasterizer_impl.cu:177), there is no cub temp storage, and the
+// scan works on per-block partial sums.
+struct GeomState {
+    float* depths;            // [P]   view-space z
+    float2* means2D;          // [P]   pixel centre
+    float4* conic_opacity;    // [P]   conic.xyz, opacity
+    float* cov3D;             // [P,6]
+    float* rgb;               // [P,3] SH colours (only when shs given)
+    uint8_t* clamped;         // [P,3]
+    uint32_t* tiles_touched;  // [P]
+    uint32_t* point_offsets;  // [P]   inclusive scan of tiles_touched
+    int* radii;               // [P]   internal radii when the caller passes NULL
+    uint32_t* block_sums;     // [ceil(P/256)+1] per-preprocess-block partial sums, then exclusive offsets
+    uint32_t* counters;       // [8]   [0] = num_rendered
+};
+struct ImgState {
+    uint2* ranges;        // [T]
+    float* final_T;       // [N]
+    uint32_t* n_contrib;  // [N]
+};
+struct BinState {
+    uint64_t* keys_unsorted;  // [R]
+    uint64_t* keys;           // [R]
+    uint32_t* vals_unsorted;  // [R]
+    uint32_t* vals;           // [R]
+    uint32_t* hist;           // radix-sort per-block digit histograms
+};
+
+size_t hsr_carve_geom(char* base, int P, GeomState* out);
+size_t hsr_carve_img(char* base, int W, int H, ImgState* out);
+size_t hsr_carve_bin(char* base, int R, BinState* out);
+uint32_t hsr_sort_hist_entries(int R);
+
+void hsr_set_error(const char* fmt, ...);
+
+#define HSR_HIP_CHECK(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            hsr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return HSR_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+// launch check: always catches launch-configuration errors; in debug mode also synchronises the
+// stream so that a kernel fault is reported at its call site (reference CHECK_CUDA, auxiliary.h:166-173)
+#define HSR_LAUNCH_CHECK(debug, stream)                            \
+    do {                                                           \
+        HSR_HIP_CHECK(hipGetLastError());                          \
+        if (debug) HSR_HIP_CHECK(hipStreamSynchronize(stream));    \
+    } while (0)
+
+// ---- kernel launchers (one translation unit per stage) ----
+struct PreprocessArgs {
+    int P, D, M, W, H;
+    const float* means3D;
+    const float* scales;
+    float scale_modifier;
+    const float* rotations;
+    const float* opacities;
+    const float* shs;
+    const float* cov3D_precomp;
+    const float* colors_precomp;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* cam_pos;
+    float tan_fovx, tan_fovy, focal_x, focal_y;
+    int* radii;
+    int prefiltered;
+    int tiles_x, tiles_y;
+};
+
+int hsr_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
+                            hipStream_t stream);
+int hsr_launch_preprocess(const PreprocessArgs& a, GeomState& g, hipStream_t stream);
+int hsr_launch_scan_block_sums(int P, GeomState& g, hipStream_t stream);
+int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, hipStream_t stream);
+int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, hipStream_t stream);
+int hsr_launch_tile_ranges(int R, int T, const uint64_t* keys, uint2* ranges, hipStream_t stream);
+
+struct RenderFwdArgs {
+    int W, H, K, semantic;
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float2* means2D;
+    const float4* conic_opacity;
+    const float* depths;
+    const float* colors;     // [P,3]
+    const float* semantics;  // [P,K] or NULL
+    float* final_T;
+    uint32_t* n_contrib;
+    float* out_color;
+    float* out_semantic;
+    float* out_depth;
+    float* out_median_depth;
+    float* out_opacity;
+    float* out_mask;  // non-semantic variant only
+};
+int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream);
+
+struct RenderBwdArgs {
+    int W, H, K, semantic, P;
+    const float* bg;  // device [3]
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float2* means2D;
+    const float4* conic_opacity;
+    const float* depths;
+    const float* colors;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const float* dL_dpix;
+    const float* dL_dpix_sem;
+    const float* dL_dpix_depth;
+    const float* dL_dpix_median;
+    const float* dL_dpix_opacity;
+    float* dL_dmean2D;    // [P,3]
+    float* dL_dconic;     // [P,4]
+    float* dL_dopacity;   // [P]
+    float* dL_dcolor;     // [P,3]
+    float* dL_dsemantics; // [P,K]
+    float* dL_ddepth;     // [P]
+};
+int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream);
+
+struct PreBwdArgs {
+    int P, D, M;
+    const float* means3D;
+    const int* radii;
+    const float* shs;
+    const uint8_t* clamped;
+    const float* scales;
+    const float* rotations;
+    float scale_modifier;
+    const float* cov3Ds;
+    const float* viewmatrix;
+    const float* projmatrix;
+    float focal_x, focal_y, tan_fovx, tan_fovy;
+    const float* campos;
+    const float* dL_dmean2D;
+    const float* dL_dconic;
+    float* dL_dmean3D;
+    float* dL_dcolor;
+    const float* dL_ddepth;
+    float* dL_dcov3D;
+    float* dL_dsh;
+    float* dL_dscale;
+    float* dL_drot;
+};
+int hsr_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t stream);
+
+#ifndef HSR_OK
+#define HSR_OK 0
+#define HSR_ERR_INVALID_ARGUMENT (-1)
+#define HSR_ERR_BUFFER_TOO_SMALL (-2)
+#define HSR_ERR_HIP (-3)
+#define HSR_ERR_NO_DEVICE (-4)
+#endif

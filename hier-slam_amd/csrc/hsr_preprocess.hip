@@ -1,0 +1,344 @@
+// hsr_preprocess.hip — per-Gaussian forward stages for gfx950:
+//   mark_visible, preprocess (cull / project / covariance / radius / tile rect / SH), the tile-count
+//   scan, (tile|depth) key emission, and tile-range identification.
+//
+// Compiled with -ffp-contract=off: every value that decides an INTEGER output (radius, tile rect,
+// tiles_touched, depth key bits) is evaluated in fp32 IEEE order with no FMA contraction, in the
+// operation order of the reference (forward.cu:74-256, auxiliary.h:41-164; GLM mat3 products sum
+// left to right, glm/detail/type_mat3x3.inl:486-520), so these outputs are bit-identical to the CPU
+// oracle.  Division and sqrt are correctly rounded (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt).
+#include "hsr_common.h"
+
+namespace {
+
+__device__ __constant__ float SH_C0 = 0.28209479177387814f;
+__device__ __constant__ float SH_C1 = 0.4886025119029199f;
+__device__ __constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                          -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                          0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                          -0.5900435899266435f};
+
+// column-major 3x3 like glm::mat3: c[col][row]
+struct M3 {
+    float c[3][3];
+};
+__device__ __forceinline__ M3 m3mul(const M3& a, const M3& b)
+{
+    M3 r;
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+            r.c[cc][rr] = a.c[0][rr] * b.c[cc][0] + a.c[1][rr] * b.c[cc][1] + a.c[2][rr] * b.c[cc][2];
+    return r;
+}
+__device__ __forceinline__ M3 m3t(const M3& a)
+{
+    M3 r;
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) r.c[cc][rr] = a.c[rr][cc];
+    return r;
+}
+
+// tile rect of a splat (reference getRect, auxiliary.h:46-56): float divide by 16 then truncation
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, uint32_t& x0, uint32_t& y0,
+                                          uint32_t& x1, uint32_t& y1)
+{
+    const float r = (float)radius;
+    int a;
+    a = (int)((px - r) / 16.0f); a = a < 0 ? 0 : a; x0 = a < gx ? a : gx;
+    a = (int)((py - r) / 16.0f); a = a < 0 ? 0 : a; y0 = a < gy ? a : gy;
+    // (p + r + BLOCK - 1) evaluates left to right in fp32: ((p + r) + 16) - 1, not p + r + 15
+    a = (int)((((px + r) + 16.0f) - 1.0f) / 16.0f); a = a < 0 ? 0 : a; x1 = a < gx ? a : gx;
+    a = (int)((((py + r) + 16.0f) - 1.0f) / 16.0f); a = a < 0 ? 0 : a; y1 = a < gy ? a : gy;
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ pts,
+                                                           const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float x = pts[3 * idx], y = pts[3 * idx + 1], z = pts[3 * idx + 2];
+    const float vz = view[2] * x + view[6] * y + view[10] * z + view[14];
+    present[idx] = !(vz <= 0.2f);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// SH -> RGB (reference computeColorFromSH, forward.cu:20-71)
+__device__ void sh_to_rgb(int idx, int deg, int max_coeffs, float px, float py, float pz, const float* campos,
+                          const float* __restrict__ shs, uint8_t* __restrict__ clamped, float* __restrict__ rgb)
+{
+    float dx = px - campos[0], dy = py - campos[1], dz = pz - campos[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    const float* sh = shs + (size_t)idx * max_coeffs * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#define SH(i) sh[(i) * 3 + c]
+        float r = SH_C0 * SH(0);
+        if (deg > 0) {
+            r = r - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+                    SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
+                if (deg > 2) {
+                    r = r + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+                        SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                        SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                        SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+                        SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+                }
+            }
+        }
+#undef SH
+        r += 0.5f;
+        clamped[3 * idx + c] = (r < 0);
+        rgb[3 * idx + c] = r > 0.0f ? r : 0.0f;
+    }
+}
+
+// One Gaussian per lane; also leaves the per-block sum of tiles_touched in block_sums[blockIdx.x]
+// so that the scan needs no extra pass over P.
+__global__ void __launch_bounds__(256) preprocess_kernel(PreprocessArgs a, GeomState g, int* __restrict__ radii)
+{
+    __shared__ uint32_t wsum[4];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    uint32_t touched = 0;
+    if (idx < a.P) {
+        int my_radius_i = 0;
+        do {
+            const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
+            const float* vm = a.viewmatrix;
+            const float* pm = a.projmatrix;
+            // in_frustum (auxiliary.h:139-164): only the view-space depth decides
+            const float tvx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+            const float tvy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+            const float tvz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+            if (tvz <= 0.2f) {
+                if (a.prefiltered) __builtin_trap();  // reference traps too (auxiliary.h:156-160)
+                break;
+            }
+            const float hx = pm[0] * px + pm[4] * py + pm[8] * pz + pm[12];
+            const float hy = pm[1] * px + pm[5] * py + pm[9] * pz + pm[13];
+            const float hw = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);
+            const float projx = hx * p_w, projy = hy * p_w;
+
+            float cov3D[6];
+            if (a.cov3D_precomp) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[(size_t)idx * 6 + i];
+            } else {
+                // computeCov3D (forward.cu:118-152)
+                const float mod = a.scale_modifier;
+                M3 S = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
+                S.c[0][0] = mod * a.scales[3 * idx];
+                S.c[1][1] = mod * a.scales[3 * idx + 1];
+                S.c[2][2] = mod * a.scales[3 * idx + 2];
+                const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+                const float r = q.x, x = q.y, y = q.z, z = q.w;
+                M3 R = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                         {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                         {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
+                const M3 Mm = m3mul(S, R);
+                const M3 Sg = m3mul(m3t(Mm), Mm);
+                cov3D[0] = Sg.c[0][0]; cov3D[1] = Sg.c[0][1]; cov3D[2] = Sg.c[0][2];
+                cov3D[3] = Sg.c[1][1]; cov3D[4] = Sg.c[1][2]; cov3D[5] = Sg.c[2][2];
+#pragma unroll
+                for (int i = 0; i < 6; i++) g.cov3D[(size_t)idx * 6 + i] = cov3D[i];
+            }
+            // computeCov2D (forward.cu:74-113)
+            const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+            const float txtz = tvx / tvz, tytz = tvy / tvz;
+            const float tx = fminf(limx, fmaxf(-limx, txtz)) * tvz;
+            const float ty = fminf(limy, fmaxf(-limy, tytz)) * tvz;
+            const M3 J = {{{a.focal_x / tvz, 0.0f, -(a.focal_x * tx) / (tvz * tvz)},
+                           {0.0f, a.focal_y / tvz, -(a.focal_y * ty) / (tvz * tvz)},
+                           {0, 0, 0}}};
+            const M3 Wm = {{{vm[0], vm[4], vm[8]}, {vm[1], vm[5], vm[9]}, {vm[2], vm[6], vm[10]}}};
+            const M3 T = m3mul(Wm, J);
+            const M3 Vrk = {{{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}}};
+            const M3 cv = m3mul(m3mul(m3t(T), m3t(Vrk)), T);
+            const float cx = cv.c[0][0] + 0.3f, cy = cv.c[0][1], cz = cv.c[1][1] + 0.3f;
+            const float det = (cx * cz - cy * cy);
+            if (det == 0.0f) break;
+            const float det_inv = 1.f / det;
+            const float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
+            const float mid = 0.5f * (cx + cz);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            // ndc2Pix in double (auxiliary.h:41-44)
+            const float pix = (float)((((double)projx + 1.0) * (double)a.W - 1.0) * 0.5);
+            const float piy = (float)((((double)projy + 1.0) * (double)a.H - 1.0) * 0.5);
+            uint32_t x0, y0, x1, y1;
+            tile_rect(pix, piy, (int)my_radius, a.tiles_x, a.tiles_y, x0, y0, x1, y1);
+            if ((x1 - x0) * (y1 - y0) == 0) break;
+            if (a.colors_precomp == nullptr) sh_to_rgb(idx, a.D, a.M, px, py, pz, a.cam_pos, a.shs, g.clamped, g.rgb);
+            g.depths[idx] = tvz;
+            my_radius_i = (int)my_radius;
+            g.means2D[idx] = make_float2(pix, piy);
+            g.conic_opacity[idx] = make_float4(conx, cony, conz, a.opacities[idx]);
+            touched = (y1 - y0) * (x1 - x0);
+        } while (0);
+        radii[idx] = my_radius_i;
+        g.tiles_touched[idx] = touched;
+    }
+    const uint32_t ws = wave_sum_u32(touched);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) g.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// block-wide exclusive scan of one value per thread (1024 threads = 16 waves)
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* smem /*[NT/64 + 1]*/, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) smem[w] = inc;
+    __syncthreads();
+    if (w == 0) {
+        uint32_t s = lane < NT / 64 ? smem[lane] : 0;
+        uint32_t si = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(si, o);
+            if (lane >= o) si += t;
+        }
+        if (lane < NT / 64) smem[lane] = si - s;  // exclusive wave offsets
+        if (lane == 63) smem[NT / 64] = si;       // total (lanes >= NT/64 carry the full sum)
+    }
+    __syncthreads();
+    total = smem[NT / 64];
+    const uint32_t r = smem[w] + inc - v;
+    __syncthreads();
+    return r;
+}
+
+// exclusive scan of the per-block sums in place (single block); total -> counters[0]
+__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblk, uint32_t* __restrict__ block_sums,
+                                                               uint32_t* __restrict__ counters)
+{
+    __shared__ uint32_t smem[1024 / 64 + 1];
+    const int per = (nblk + 1023) / 1024;
+    const int beg = threadIdx.x * per;
+    uint32_t local = 0;
+    for (int i = 0; i < per; i++) {
+        const int j = beg + i;
+        if (j < nblk) local += block_sums[j];
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan<1024>(local, smem, total);
+    for (int i = 0; i < per; i++) {
+        const int j = beg + i;
+        if (j < nblk) {
+            const uint32_t v = block_sums[j];
+            block_sums[j] = run;
+            run += v;
+        }
+    }
+    if (threadIdx.x == 0) counters[0] = total;
+}
+
+// Finishes the scan (point_offsets = inclusive sum, as cub::DeviceScan::InclusiveSum at
+// rasterizer_impl.cu:281) and emits one (tile|depth, id) pair per touched tile, row-major over the
+// rect exactly like the reference's duplicateWithKeys (rasterizer_impl.cu:70-111).
+__global__ void __launch_bounds__(256) duplicate_kernel(int P, const int* __restrict__ radii, int tiles_x, int tiles_y,
+                                                        GeomState g, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    __shared__ uint32_t smem[256 / 64 + 1];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t touched = idx < P ? g.tiles_touched[idx] : 0;
+    uint32_t total;
+    uint32_t off = block_exclusive_scan<256>(touched, smem, total) + g.block_sums[blockIdx.x];
+    if (idx >= P) return;
+    g.point_offsets[idx] = off + touched;
+    const int radius = radii[idx];
+    if (radius > 0) {
+        const float2 xy = g.means2D[idx];
+        uint32_t x0, y0, x1, y1;
+        tile_rect(xy.x, xy.y, radius, tiles_x, tiles_y, x0, y0, x1, y1);
+        const uint64_t dbits = (uint64_t)__float_as_uint(g.depths[idx]);
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) {
+                keys[off] = ((uint64_t)(y * (uint32_t)tiles_x + x) << 32) | dbits;
+                vals[off] = (uint32_t)idx;
+                off++;
+            }
+    }
+}
+
+// reference identifyTileRanges (rasterizer_impl.cu:116-138)
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0)
+        ranges[cur].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (cur != prev) {
+            ranges[prev].y = idx;
+            ranges[cur].x = idx;
+        }
+    }
+    if (idx == L - 1) ranges[cur].y = L;
+}
+
+}  // namespace
+
+int hsr_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
+                            hipStream_t stream)
+{
+    (void)proj;
+    if (P <= 0) return HSR_OK;
+    mark_visible_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, means3D, view, present);
+    return HSR_OK;
+}
+
+int hsr_launch_preprocess(const PreprocessArgs& a, GeomState& g, hipStream_t stream)
+{
+    preprocess_kernel<<<(a.P + 255) / 256, 256, 0, stream>>>(a, g, a.radii);
+    return HSR_OK;
+}
+
+int hsr_launch_scan_block_sums(int P, GeomState& g, hipStream_t stream)
+{
+    scan_block_sums_kernel<<<1, 1024, 0, stream>>>((P + 255) / 256, g.block_sums, g.counters);
+    return HSR_OK;
+}
+
+int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, hipStream_t stream)
+{
+    duplicate_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, radii, tiles_x, tiles_y, g, b.keys_unsorted, b.vals_unsorted);
+    return HSR_OK;
+}
+
+int hsr_launch_tile_ranges(int R, int T, const uint64_t* keys, uint2* ranges, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, stream);
+    if (e != hipSuccess) {
+        hsr_set_error("hipMemsetAsync(ranges) failed: %s", hipGetErrorString(e));
+        return HSR_ERR_HIP;
+    }
+    if (R > 0) tile_ranges_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, keys, ranges);
+    return HSR_OK;
+}

@@ -1,0 +1,277 @@
+// hsr_render_bwd.hip — 16x16-tile backward alpha compositing for gfx950 (wave64, 4 waves per tile).
+//
+// Per-pixel semantics follow the reference's backward renderCUDA / renderCUDA_SEM
+// (cuda_rasterizer/backward.cu:472-666, :669-899): back-to-front re-traversal from final_T /
+// n_contrib, T recovered as T/(1-alpha), the same alpha thresholds, the bg term, the median-depth
+// gradient at the T=0.5 crossing, final opacity treated as a blended channel of ones whose colour
+// gradient is ADDED to dL_dopacity (backward.cu:628-632, :859-864), and — as observed in the
+// reference — no semantic->alpha term (backward.cu:834 reads a scratch buffer that is never
+// written, rasterizer_impl.cu:673-674): the semantic loss reaches dL_dsemantics only.
+//
+// The CDNA4 design point is the accumulation.  The reference issues 11+K fp32 global atomicAdds per
+// (pixel, splat) pair (backward.cu:616-663, :828-896).  Here the 10+K per-lane terms of one splat
+// are summed across the 64 lanes of a wave with a *transposing* butterfly: each stage pairs two
+// registers and halves the lane set (v_permlane32_swap, v_permlane16_swap, then DPP row_ror:8 /
+// row_half_mirror / quad_perm), so N values cost ~2.4 N instructions instead of 6 N and end up one
+// per lane (lane l holds the total of value bitrev6(l)).  One global_atomic_add_f32 wave-instruction
+// per (wave, splat) then carries all 10+K sums.  Waves in which no lane accepts a splat skip it.
+#include "hsr_common.h"
+
+namespace {
+
+// ---- cross-lane helpers (gfx950) ----
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+
+// lanes 0-31 <- x.lo + x.hi ; lanes 32-63 <- y.lo + y.hi
+__device__ __forceinline__ float pair32(float x, float y)
+{
+    const uint2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// rows (16 lanes) with bit4 = 0 <- x.row(2i) + x.row(2i+1) ; bit4 = 1 <- y.row(2i) + y.row(2i+1)
+__device__ __forceinline__ float pair16(float x, float y)
+{
+    const uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+// lanes with `bit` clear keep x (+ partner's x), lanes with it set keep y (+ partner's y)
+template <int CTRL>
+__device__ __forceinline__ float pair_dpp(float x, float y, bool bit)
+{
+    const float keep = bit ? y : x;
+    const float send = bit ? x : y;
+    return keep + dpp_mov<CTRL>(send);
+}
+
+constexpr int DPP_ROW_ROR8 = 0x128;
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm [2,3,0,1]
+constexpr int DPP_QUAD_XOR1 = 0xB1;  // quad_perm [1,0,3,2]
+
+// Sums each of the N per-lane values over the 64 lanes of the wave.  Returns, in lane l, the total of
+// v[bitrev6(l)] (garbage-free zero where bitrev6(l) >= N is not guaranteed: callers mask by index).
+template <int M>
+__device__ __forceinline__ float elem_or_zero(const float (&x)[M], int i)
+{
+    return i < M ? x[i < M ? i : 0] : 0.f;
+}
+
+template <int N>
+__device__ __forceinline__ float wave_reduce_transpose(const float (&v)[N], int lane)
+{
+    static_assert(N >= 1 && N <= 64, "at most one value per lane");
+    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
+    static_assert((N5 + 1) / 2 == 1, "six stages reduce to one register");
+    float a[N1], b[N2], c[N3], d[N4], e[N5];
+#pragma unroll
+    for (int i = 0; i < N1; i++) a[i] = pair32(v[2 * i], elem_or_zero(v, 2 * i + 1));
+#pragma unroll
+    for (int i = 0; i < N2; i++) b[i] = pair16(a[2 * i], elem_or_zero(a, 2 * i + 1));
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < N3; i++) c[i] = pair_dpp<DPP_ROW_ROR8>(b[2 * i], elem_or_zero(b, 2 * i + 1), b3);
+#pragma unroll
+    for (int i = 0; i < N4; i++) d[i] = pair_dpp<DPP_ROW_HALF_MIRROR>(c[2 * i], elem_or_zero(c, 2 * i + 1), b2);
+#pragma unroll
+    for (int i = 0; i < N5; i++) e[i] = pair_dpp<DPP_QUAD_XOR2>(d[2 * i], elem_or_zero(d, 2 * i + 1), b1);
+    return pair_dpp<DPP_QUAD_XOR1>(e[0], elem_or_zero(e, 1), b0);
+}
+
+__device__ __forceinline__ int bitrev6(int l)
+{
+    return ((l & 1) << 5) | ((l & 2) << 3) | ((l & 4) << 1) | ((l & 8) >> 1) | ((l & 16) >> 3) | ((l & 32) >> 5);
+}
+
+template <int KC>
+struct BwdCfg {
+    static constexpr int NV = 10 + KC;  // mean2D.xy, conic.xyw, opacity, rgb, depth, sem[KC]
+    static constexpr int NV_SEMONLY = KC;
+};
+
+// BASE: this launch produces the 10 geometric/colour sums (and the first KC semantic channels);
+// !BASE: semantic channels [c0, c0+KC) only (generic-K chunking).
+template <int KC, bool BASE>
+__global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0)
+{
+    constexpr int BATCH = 256;
+    constexpr int NV = BASE ? 10 + KC : (KC > 0 ? KC : 1);
+    __shared__ float4 s_geo[BATCH];  // x, y, conic.x, conic.y
+    __shared__ float2 s_co[BATCH];   // conic.z, opacity
+    __shared__ float4 s_col[BATCH];  // r, g, b, depth
+    __shared__ int s_id[BATCH];
+    __shared__ int s_wmax[4];
+
+    const int tiles_x = (a.W + HSR_TILE_X - 1) / HSR_TILE_X;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int px = tx * HSR_TILE_X + (t & 15), py = ty * HSR_TILE_Y + (t >> 4);
+    const bool inside = px < a.W && py < a.H;
+    const size_t N = (size_t)a.W * a.H;
+    const size_t pix_id = (size_t)a.W * py + px;
+    const float pfx = (float)px, pfy = (float)py;
+    const uint2 range = a.ranges[tile];
+
+    const float T_final = inside ? a.final_T[pix_id] : 0.f;
+    float T = T_final;
+    const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
+
+    // nothing behind the tile's farthest contributor can receive gradient: start there
+    int wmax = last_contributor;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) s_wmax[wv] = wmax;
+    __syncthreads();
+    const int hi_all = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+
+    float dpx0 = 0, dpx1 = 0, dpx2 = 0, dpd = 0, dpm = 0, dpo = 0;
+    float dsem[KC > 0 ? KC : 1];
+#pragma unroll
+    for (int c = 0; c < (KC > 0 ? KC : 1); c++) dsem[c] = 0.f;
+    if (inside) {
+        if (BASE) {
+            dpx0 = a.dL_dpix[pix_id];
+            dpx1 = a.dL_dpix[N + pix_id];
+            dpx2 = a.dL_dpix[2 * N + pix_id];
+            dpd = a.dL_dpix_depth[pix_id];
+            dpm = a.dL_dpix_median[pix_id];
+            dpo = a.dL_dpix_opacity[pix_id];
+        }
+#pragma unroll
+        for (int c = 0; c < KC; c++)
+            if (c0 + c < a.K) dsem[c] = a.dL_dpix_sem[(size_t)(c0 + c) * N + pix_id];
+    }
+    const float bg_dot = BASE ? a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2 : 0.f;
+    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+
+    float acc0 = 0, acc1 = 0, acc2 = 0, accd = 0, acco = 0;
+    float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_depth = 0, last_op = 0;
+
+    // per-lane atomic target for the value this lane ends up holding after the transposing reduction
+    const int myv = bitrev6(lane);
+    float* tgt_base = nullptr;
+    int tgt_stride = 0;
+    if (BASE) {
+        if (myv < 2) { tgt_base = a.dL_dmean2D + myv; tgt_stride = 3; }
+        else if (myv < 5) { tgt_base = a.dL_dconic + (myv == 4 ? 3 : myv - 2); tgt_stride = 4; }
+        else if (myv == 5) { tgt_base = a.dL_dopacity; tgt_stride = 1; }
+        else if (myv < 9) { tgt_base = a.dL_dcolor + (myv - 6); tgt_stride = 3; }
+        else if (myv == 9) { tgt_base = a.dL_ddepth; tgt_stride = 1; }
+        else if (myv < NV && c0 + (myv - 10) < a.K) { tgt_base = a.dL_dsemantics + c0 + (myv - 10); tgt_stride = a.K; }
+    } else {
+        if (myv < NV && c0 + myv < a.K) { tgt_base = a.dL_dsemantics + c0 + myv; tgt_stride = a.K; }
+    }
+
+    for (int hi = hi_all; hi > 0; hi -= BATCH) {
+        const int cnt = min(BATCH, hi);
+        __syncthreads();
+        if (t < cnt) {
+            // j = 0 is the farthest entry of this batch (list position hi-1), like the reference's
+            // reverse staging (backward.cu:562, :771)
+            const int id = (int)a.point_list[range.x + hi - 1 - t];
+            const float2 xy = a.means2D[id];
+            const float4 co = a.conic_opacity[id];
+            s_id[t] = id;
+            s_geo[t] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_co[t] = make_float2(co.z, co.w);
+            if (BASE)
+                s_col[t] = make_float4(a.colors[3 * (size_t)id], a.colors[3 * (size_t)id + 1], a.colors[3 * (size_t)id + 2],
+                                       a.depths[id]);
+        }
+        __syncthreads();
+        if (hi - cnt >= wmax) continue;  // this wave's pixels all stopped in front of this batch
+
+        for (int j = 0; j < cnt; j++) {
+            const int pos = hi - 1 - j;  // 0-based list position == reference `contributor` after decrement
+            const float4 g = s_geo[j];
+            const float2 co = s_co[j];
+            const float dx = g.x - pfx, dy = g.y - pfy;
+            const float power = -0.5f * (g.z * dx * dx + co.x * dy * dy) - g.w * dx * dy;
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, co.y * G);
+            const bool active = pos < last_contributor && power <= 0.0f && alpha >= 1.0f / 255.0f;
+            if (__ballot(active) == 0ull) continue;
+
+            const float one_m_a = 1.0f - alpha;
+            const float test_T = T / one_m_a;
+            const float w = active ? alpha * test_T : 0.f;
+            float v[NV];
+            if (BASE) {
+                const float4 cd = s_col[j];
+                float dL_dalpha = 0.f;
+                // colour channels (backward.cu:604-617)
+                const float a0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                const float a1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                const float a2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                dL_dalpha += (cd.x - a0) * dpx0;
+                dL_dalpha += (cd.y - a1) * dpx1;
+                dL_dalpha += (cd.z - a2) * dpx2;
+                v[6] = w * dpx0;
+                v[7] = w * dpx1;
+                v[8] = w * dpx2;
+                // depth (+ median-depth gradient at the T = 0.5 crossing, backward.cu:618-626)
+                const float ad = last_alpha * last_depth + (1.f - last_alpha) * accd;
+                dL_dalpha += (cd.w - ad) * dpd;
+                v[9] = w * dpd + ((active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f);
+                // final opacity as a channel of ones (backward.cu:628-632)
+                const float ao = last_alpha * last_op + (1.f - last_alpha) * acco;
+                dL_dalpha += (1.f - ao) * dpo;
+                dL_dalpha *= test_T;
+                dL_dalpha += (-T_final / one_m_a) * bg_dot;
+                if (!active) dL_dalpha = 0.f;
+                const float dL_dG = co.y * dL_dalpha;
+                const float Gs = active ? G : 0.f;  // exp(power>0) may be inf on rejected lanes: keep it out of the sums
+                const float gdx = Gs * dx, gdy = Gs * dy;
+                const float dG_ddelx = -gdx * g.z - gdy * g.w;
+                const float dG_ddely = -gdy * co.x - gdx * g.w;
+                v[0] = dL_dG * dG_ddelx * ddelx_dx;
+                v[1] = dL_dG * dG_ddely * ddely_dy;
+                v[2] = -0.5f * gdx * dx * dL_dG;
+                v[3] = -0.5f * gdx * dy * dL_dG;
+                v[4] = -0.5f * gdy * dy * dL_dG;
+                v[5] = w * dpo + Gs * dL_dalpha;
+                if (active) {
+                    acc0 = a0; acc1 = a1; acc2 = a2; accd = ad; acco = ao;
+                    lc0 = cd.x; lc1 = cd.y; lc2 = cd.z; last_depth = cd.w; last_op = 1.f;
+                    last_alpha = alpha;
+                }
+#pragma unroll
+                for (int c = 0; c < KC; c++) v[10 + c] = w * dsem[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < KC; c++) v[c] = w * dsem[c];
+            }
+            if (active) T = test_T;
+
+            const float total = wave_reduce_transpose<NV>(v, lane);
+            if (tgt_base) atomicAdd(tgt_base + (size_t)s_id[j] * tgt_stride, total);
+        }
+    }
+}
+
+}  // namespace
+
+int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
+{
+    const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
+    const dim3 grid(tiles), block(256);
+    if (!a.semantic || a.K == 0) {
+        render_bwd_kernel<0, true><<<grid, block, 0, stream>>>(a, 0);
+        return HSR_OK;
+    }
+    switch (a.K) {
+    case 16: render_bwd_kernel<16, true><<<grid, block, 0, stream>>>(a, 0); break;
+    case 26: render_bwd_kernel<26, true><<<grid, block, 0, stream>>>(a, 0); break;
+    default:
+        // base sums + first 32 channels, then 32-channel chunks (K = 74, 102 and any other K)
+        render_bwd_kernel<32, true><<<grid, block, 0, stream>>>(a, 0);
+        for (int c0 = 32; c0 < a.K; c0 += 32) render_bwd_kernel<32, false><<<grid, block, 0, stream>>>(a, c0);
+        break;
+    }
+    return HSR_OK;
+}

@@ -1,0 +1,176 @@
+// hsr_render_fwd.hip — 16x16-tile forward alpha compositing for gfx950 (wave64, 4 waves per tile).
+//
+// Follows the per-pixel semantics of the reference's renderCUDA / renderCUDA_SEM
+// (cuda_rasterizer/forward.cu:261-398, :400-538): front-to-back over the tile's depth-sorted list,
+// power>0 and alpha<1/255 skipped, alpha clamped at 0.99, pixel terminated when T(1-alpha) < 1e-4,
+// median depth = depth of the splat where T crosses 0.5 (default 15), NO background blend.
+//
+// What is different from the reference, by design for CDNA4:
+//   * every per-splat quantity the blend needs — centre, conic, opacity, colour, depth and the K
+//     semantic features — is staged ONCE per tile batch into LDS with coalesced loads and then read
+//     as wave-uniform broadcasts; the reference gathers colour/depth/semantics from global memory per
+//     pixel per splat (forward.cu:503-508).
+//   * a splat that no lane of a wave accepts costs that wave only the alpha test (wave ballot), and a
+//     wave whose 64 pixels are all terminated stops blending while it keeps helping to stage.
+//   * K is a template parameter of the kernel but a run-time argument of the library: known tree
+//     sizes get one fused launch, any other K is rendered in 32-channel chunks.
+#include "hsr_common.h"
+
+namespace {
+
+template <int KC>
+struct FwdCfg {
+    // LDS per staged splat: 16 (x,y,cx,cy) + 8 (cz,op) + 16 (r,g,b,depth) + 4 (id) + 4*KP
+    static constexpr int KP = (KC + 3) & ~3;
+    static constexpr int BATCH = KC <= 32 ? 256 : (KC <= 80 ? 128 : 64);
+};
+
+template <int KC, bool BASE, bool MASK>
+__global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0)
+{
+    constexpr int KP = FwdCfg<KC>::KP;
+    constexpr int BATCH = FwdCfg<KC>::BATCH;
+    __shared__ float4 s_geo[BATCH];   // x, y, conic.x, conic.y
+    __shared__ float2 s_co[BATCH];    // conic.z, opacity
+    __shared__ float4 s_col[BATCH];   // r, g, b, depth
+    __shared__ int s_id[BATCH];
+    __shared__ float s_sem[KC > 0 ? BATCH * KP : 1];
+    __shared__ int s_wdone[4];
+
+    const int tiles_x = (a.W + HSR_TILE_X - 1) / HSR_TILE_X;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int t = threadIdx.x, wv = t >> 6;
+    const int px = tx * HSR_TILE_X + (t & 15), py = ty * HSR_TILE_Y + (t >> 4);
+    const bool inside = px < a.W && py < a.H;
+    const size_t N = (size_t)a.W * a.H;
+    const size_t pix_id = (size_t)a.W * py + px;
+    const float pfx = (float)px, pfy = (float)py;
+
+    const uint2 range = a.ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    float T = 1.0f;
+    uint32_t last_contributor = 0;
+    float C0 = 0, C1 = 0, C2 = 0, Dd = 0, Mm = 0, median_D = 15.0f;
+    float S[KC > 0 ? KC : 1];
+#pragma unroll
+    for (int c = 0; c < (KC > 0 ? KC : 1); c++) S[c] = 0.f;
+    bool done = !inside;
+
+    for (int start = 0; start < n; start += BATCH) {
+        const bool wave_done = __ballot(!done) == 0ull;
+        if ((t & 63) == 0) s_wdone[wv] = wave_done;
+        __syncthreads();  // also: everyone has finished reading the previous batch
+        if (s_wdone[0] & s_wdone[1] & s_wdone[2] & s_wdone[3]) break;
+        const int cnt = min(BATCH, n - start);
+        if (t < cnt) {
+            const int id = (int)a.point_list[range.x + start + t];
+            const float2 xy = a.means2D[id];
+            const float4 co = a.conic_opacity[id];
+            s_id[t] = id;
+            s_geo[t] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_co[t] = make_float2(co.z, co.w);
+            if (BASE)
+                s_col[t] = make_float4(a.colors[3 * (size_t)id], a.colors[3 * (size_t)id + 1], a.colors[3 * (size_t)id + 2],
+                                       a.depths[id]);
+            else
+                s_col[t] = make_float4(0, 0, 0, a.depths[id]);
+        }
+        if (KC > 0) {
+            __syncthreads();
+            // consecutive lanes read consecutive floats of a feature row: coalesced 4*KC-byte segments
+            for (int e = t; e < cnt * KC; e += 256) {
+                const int s = e / KC, c = e - s * KC;
+                const int ch = c0 + c;
+                s_sem[s * KP + c] = ch < a.K ? a.semantics[(size_t)s_id[s] * a.K + ch] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (wave_done) continue;
+
+        for (int j = 0; j < cnt; j++) {
+            const float4 g = s_geo[j];
+            const float2 co = s_co[j];
+            const float dx = g.x - pfx, dy = g.y - pfy;
+            const float power = -0.5f * (g.z * dx * dx + co.x * dy * dy) - g.w * dx * dy;
+            const float alpha = fminf(0.99f, co.y * __expf(power));
+            bool contrib = !done && power <= 0.0f && alpha >= 1.0f / 255.0f;
+            const float test_T = T * (1.0f - alpha);
+            if (contrib && test_T < 0.0001f) {
+                done = true;
+                contrib = false;
+            }
+            if (__ballot(contrib) == 0ull) continue;
+            const float w = contrib ? alpha * T : 0.f;
+            const float4 cd = s_col[j];
+            if (BASE) {
+                C0 = fmaf(cd.x, w, C0);
+                C1 = fmaf(cd.y, w, C1);
+                C2 = fmaf(cd.z, w, C2);
+                Dd = fmaf(cd.w, w, Dd);
+                if (MASK) Mm += w;
+                if (contrib && T > 0.5f && test_T < 0.5f) median_D = cd.w;
+            }
+            if (KC > 0) {
+                const float4* row = reinterpret_cast<const float4*>(&s_sem[j * KP]);
+#pragma unroll
+                for (int q = 0; q < KP / 4; q++) {
+                    const float4 f = row[q];
+                    if (4 * q + 0 < KC) S[4 * q + 0] = fmaf(f.x, w, S[4 * q + 0]);
+                    if (4 * q + 1 < KC) S[4 * q + 1] = fmaf(f.y, w, S[4 * q + 1]);
+                    if (4 * q + 2 < KC) S[4 * q + 2] = fmaf(f.z, w, S[4 * q + 2]);
+                    if (4 * q + 3 < KC) S[4 * q + 3] = fmaf(f.w, w, S[4 * q + 3]);
+                }
+            }
+            if (contrib) {
+                T = test_T;
+                last_contributor = (uint32_t)(start + j + 1);
+            }
+        }
+    }
+
+    if (inside) {
+        if (BASE) {
+            a.final_T[pix_id] = T;
+            a.n_contrib[pix_id] = last_contributor;
+            a.out_color[pix_id] = C0;
+            a.out_color[N + pix_id] = C1;
+            a.out_color[2 * N + pix_id] = C2;
+            a.out_depth[pix_id] = Dd;
+            a.out_median_depth[pix_id] = median_D;
+            a.out_opacity[pix_id] = 1.0f - T;
+            if (MASK) a.out_mask[pix_id] = Mm;
+        }
+        if (KC > 0) {
+#pragma unroll
+            for (int c = 0; c < KC; c++)
+                if (c0 + c < a.K) a.out_semantic[(size_t)(c0 + c) * N + pix_id] = S[c];
+        }
+    }
+}
+
+}  // namespace
+
+int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
+{
+    const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
+    const dim3 grid(tiles), block(256);
+    if (!a.semantic) {
+        render_fwd_kernel<0, true, true><<<grid, block, 0, stream>>>(a, 0);
+        return HSR_OK;
+    }
+    switch (a.K) {
+    case 0: render_fwd_kernel<0, true, false><<<grid, block, 0, stream>>>(a, 0); break;
+    case 16: render_fwd_kernel<16, true, false><<<grid, block, 0, stream>>>(a, 0); break;   // ScanNet tree
+    case 26: render_fwd_kernel<26, true, false><<<grid, block, 0, stream>>>(a, 0); break;   // Replica tree
+    case 74: render_fwd_kernel<74, true, false><<<grid, block, 0, stream>>>(a, 0); break;   // ScanNet large tree
+    case 102: render_fwd_kernel<102, true, false><<<grid, block, 0, stream>>>(a, 0); break; // Replica flat
+    default:
+        // any other K: 32-channel chunks; the first chunk also produces the base outputs
+        render_fwd_kernel<32, true, false><<<grid, block, 0, stream>>>(a, 0);
+        for (int c0 = 32; c0 < a.K; c0 += 32) render_fwd_kernel<32, false, false><<<grid, block, 0, stream>>>(a, c0);
+        break;
+    }
+    return HSR_OK;
+}

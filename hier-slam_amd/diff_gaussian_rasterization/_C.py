@@ -1,0 +1,314 @@
+"""`diff_gaussian_rasterization._C` — torch-facing glue over libhsr_rast.so (the gfx950 HIP library).
+
+Mirrors the five entry points the reference exports from its pybind module (ext.cpp:15-23,
+rasterize_points.h:18-125) with the same argument order and return tuples, so
+`diff_gaussian_rasterization/__init__.py` — and through it scripts/hierslam.py — binds to it unchanged:
+
+    rasterize_gaussians, rasterize_gaussians_backward, mark_visible,
+    rasterize_gaussians_semantic, rasterize_gaussians_backward_semantic
+
+The glue only allocates tensors and hands raw device pointers to the C ABI declared in
+include/hsr_rasterizer.h (ctypes; no torch types cross the boundary).  There is NO fallback path: if the
+shared library is missing or the tensors are not on a HIP device, these functions raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get("HSR_RAST_LIB", os.path.join(os.path.dirname(_HERE), "libhsr_rast.so"))
+
+NUM_CHANNELS = 3  # reference config.h:15
+
+
+class _HsrBuffer(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("capacity", C.c_size_t), ("grow", C.c_void_p), ("user", C.c_void_p)]
+
+
+_GROW_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class _StateLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "geom_depths", "geom_means2D", "geom_conic_opacity", "geom_cov3D", "geom_rgb", "geom_clamped",
+        "geom_tiles_touched", "geom_point_offsets", "geom_radii",
+        "bin_keys_unsorted", "bin_keys", "bin_vals_unsorted", "bin_vals",
+        "img_ranges", "img_final_T", "img_n_contrib")]
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            "diff_gaussian_rasterization: HIP library not found at %s — build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C hier-slam_amd/csrc`. "
+            "There is no CPU fallback." % _LIB_PATH)
+    lib = C.CDLL(_LIB_PATH)
+    vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    bp = C.POINTER(_HsrBuffer)
+    lib.hsr_required_geometry_bytes.restype = sz
+    lib.hsr_required_geometry_bytes.argtypes = [ci]
+    lib.hsr_required_image_bytes.restype = sz
+    lib.hsr_required_image_bytes.argtypes = [ci, ci]
+    lib.hsr_required_binning_bytes.restype = sz
+    lib.hsr_required_binning_bytes.argtypes = [ci]
+    lib.hsr_last_error.restype = C.c_char_p
+    lib.hsr_version.restype = C.c_char_p
+    lib.hsr_mark_visible.restype = ci
+    lib.hsr_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
+    lib.hsr_forward.restype = ci
+    lib.hsr_forward.argtypes = [bp, bp, bp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, ci,
+                                vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.hsr_forward_semantic.restype = ci
+    lib.hsr_forward_semantic.argtypes = [bp, bp, bp, ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp,
+                                         cf, cf, ci, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.hsr_backward.restype = ci
+    lib.hsr_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp,
+                                 vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.hsr_backward_semantic.restype = ci
+    lib.hsr_backward_semantic.argtypes = [ci, ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf,
+                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.hsr_get_state_layout.restype = ci
+    lib.hsr_get_state_layout.argtypes = [ci, ci, ci, ci, C.POINTER(_StateLayout)]
+    return lib
+
+
+_lib = _load()
+
+# last num_rendered seen per (device, P, W, H): sizes the binning buffer up front so that the steady
+# state needs no grow callback (the reference resizes through a callback every call,
+# rasterize_points.cu:27-33)
+_binning_hint = {}
+
+
+def version():
+    return _lib.hsr_version().decode()
+
+
+def _fail(rc, what):
+    raise RuntimeError("%s failed (code %d): %s" % (what, rc, _lib.hsr_last_error().decode()))
+
+
+def _ptr(t):
+    """Device pointer of a contiguous fp32/int32 tensor, or NULL for the reference's empty placeholders."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _prep(t, dev, dtype=torch.float32):
+    """contiguous tensor on `dev` (reference: `.contiguous().data<float>()`, rasterize_points.cu:104-124)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != dev:
+        raise RuntimeError("diff_gaussian_rasterization: tensor on %s, expected %s" % (t.device, dev))
+    if t.dtype != dtype:
+        raise RuntimeError("diff_gaussian_rasterization: tensor dtype %s, expected %s" % (t.dtype, dtype))
+    return t.contiguous()
+
+
+def _require_gpu(means3D):
+    if not means3D.is_cuda:
+        raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got %s); "
+                           "this build has no CPU path" % means3D.device)
+
+
+class _Grower:
+    """Adapts a torch uint8 tensor to hsr_buffer: pre-sized allocation + grow callback."""
+
+    def __init__(self, nbytes, dev):
+        self.dev = dev
+        self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        self.cb = _GROW_FN(self._grow)
+        self.buf = _HsrBuffer(self.t.data_ptr() if nbytes else None, int(nbytes), C.cast(self.cb, C.c_void_p), None)
+
+    def _grow(self, nbytes, _user):
+        try:
+            self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
+            return self.t.data_ptr()
+        except Exception:  # report failure through the C return code
+            return None
+
+
+def _forward_common(semantic, background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
+                    cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                    campos, prefiltered, debug):
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:60-62
+    _require_gpu(means3D)
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    K = 0
+    if semantic:
+        if semantics is not None and (semantics.numel() > 0 or semantics.ndimension() == 2):
+            # the reference never checks this shape against its compile-time NUM_SEMANTIC (silent OOB)
+            if semantics.ndimension() != 2 or semantics.size(0) != P:
+                raise RuntimeError("semantics_precomp must have dimensions (num_points, K)")
+            K = int(semantics.size(1))
+    fopt = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        # every pixel of every output is written by the render kernel, so no zero-fill is needed
+        # (the reference zero-fills with torch::full first, rasterize_points.cu:71-76)
+        out_color = torch.empty((NUM_CHANNELS, H, W), **fopt)
+        out_depth = torch.empty((1, H, W), **fopt)
+        out_median = torch.empty((1, H, W), **fopt)
+        out_opacity = torch.empty((1, H, W), **fopt)
+        out_aux = torch.empty((K if semantic else 1, H, W), **fopt)  # semantic map or mask
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        if P == 0:
+            geom = _Grower(0, dev); binning = _Grower(0, dev); img = _Grower(0, dev)
+        else:
+            geom = _Grower(_lib.hsr_required_geometry_bytes(P), dev)
+            img = _Grower(_lib.hsr_required_image_bytes(W, H), dev)
+            hint = _binning_hint.get((dev.index, P, W, H), 4 * P)
+            binning = _Grower(_lib.hsr_required_binning_bytes(int(hint * 1.25) + 1024), dev)
+        M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+        tens = [_prep(x, dev) for x in (background, means3D, sh, colors, semantics if semantic else None, opacity, scales,
+                                        rotations, cov3D_precomp, viewmatrix, projmatrix, campos)]
+        bg_, m3_, sh_, col_, sem_, op_, sc_, rot_, cov_, vm_, pm_, cp_ = tens
+        if semantic:
+            rc = _lib.hsr_forward_semantic(
+                C.byref(geom.buf), C.byref(binning.buf), C.byref(img.buf), P, int(degree), M, K, _ptr(bg_), W, H, _ptr(m3_),
+                _ptr(sh_), _ptr(col_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(cov_),
+                _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                _ptr(out_color), _ptr(out_aux), _ptr(out_depth), _ptr(out_median), _ptr(out_opacity), _ptr(radii),
+                int(bool(debug)), stream)
+        else:
+            rc = _lib.hsr_forward(
+                C.byref(geom.buf), C.byref(binning.buf), C.byref(img.buf), P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_),
+                _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(cov_),
+                _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                _ptr(out_color), _ptr(out_depth), _ptr(out_median), _ptr(out_opacity), _ptr(out_aux), _ptr(radii),
+                int(bool(debug)), stream)
+        if rc < 0:
+            _fail(rc, "rasterize_gaussians_semantic" if semantic else "rasterize_gaussians")
+        if P:
+            _binning_hint[(dev.index, P, W, H)] = rc
+    return rc, out_color, out_aux, out_depth, out_median, out_opacity, radii, geom.t, binning.t, img.t
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """RasterizeGaussiansCUDA (rasterize_points.cu:36-127) ->
+    (rendered, color, depth, median_depth, opacity, mask, radii, geomBuffer, binningBuffer, imgBuffer)."""
+    r, color, mask, depth, median, opac, radii, g, b, i = _forward_common(
+        False, background, means3D, colors, None, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+        projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug)
+    return r, color, depth, median, opac, mask, radii, g, b, i
+
+
+def rasterize_gaussians_semantic(background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
+                                 degree, campos, prefiltered, debug):
+    """RasterizeGaussiansCUDA_semantic (rasterize_points.cu:241-336) ->
+    (rendered, color, semantic, depth, median_depth, opacity, radii, geomBuffer, binningBuffer, imgBuffer)."""
+    r, color, sem, depth, median, opac, radii, g, b, i = _forward_common(
+        True, background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+        projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug)
+    return r, color, sem, depth, median, opac, radii, g, b, i
+
+
+def _backward_common(semantic, background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
+                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic,
+                     dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
+                     binningBuffer, imageBuffer, debug):
+    _require_gpu(means3D)
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    K = int(dL_dout_semantic.size(0)) if semantic else 0
+    fopt = dict(dtype=torch.float32, device=dev)
+    new = torch.zeros if P == 0 else torch.empty  # the library overwrites every element when P > 0
+    dL_dmeans3D = new((P, 3), **fopt)
+    dL_dmeans2D = new((P, 3), **fopt)
+    dL_dcolors = new((P, NUM_CHANNELS), **fopt)
+    dL_dsemantics = new((P, K), **fopt)
+    dL_ddepths = new((P, 1), **fopt)
+    dL_dconic = new((P, 2, 2), **fopt)
+    dL_dopacity = new((P, 1), **fopt)
+    dL_dcov3D = new((P, 6), **fopt)
+    dL_dsh = new((P, M, 3), **fopt)
+    dL_dscales = new((P, 3), **fopt)
+    dL_drotations = new((P, 4), **fopt)
+    if P != 0:
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            tens = [_prep(x, dev) for x in (background, means3D, sh, colors, semantics if semantic else None, scales,
+                                            rotations, cov3D_precomp, viewmatrix, projmatrix, campos, dL_dout_color,
+                                            dL_dout_semantic if semantic else None, dL_dout_depth, dL_dout_median_depth,
+                                            dL_dout_final_opacity)]
+            bg_, m3_, sh_, col_, sem_, sc_, rot_, cov_, vm_, pm_, cp_, gcol, gsem, gdep, gmed, gop = tens
+            radii_ = _prep(radii, dev, torch.int32)
+            common_tail = (_ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
+                           int(bool(debug)), stream)
+            if semantic:
+                rc = _lib.hsr_backward_semantic(
+                    P, int(degree), M, K, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sem_), _ptr(sc_),
+                    float(scale_modifier), _ptr(rot_), _ptr(cov_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx),
+                    float(tan_fovy), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                    _ptr(gcol), _ptr(gsem), _ptr(gdep), _ptr(gmed), _ptr(gop),
+                    _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dsemantics),
+                    _ptr(dL_ddepths), *common_tail)
+            else:
+                rc = _lib.hsr_backward(
+                    P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
+                    float(scale_modifier), _ptr(rot_), _ptr(cov_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx),
+                    float(tan_fovy), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                    _ptr(gcol), _ptr(gdep), _ptr(gmed), _ptr(gop),
+                    _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), *common_tail)
+            if rc < 0:
+                _fail(rc, "rasterize_gaussians_backward_semantic" if semantic else "rasterize_gaussians_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                 dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
+                                 binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:129-215) -> 8 tensors
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    g = _backward_common(False, background, means3D, radii, colors, None, scales, rotations, scale_modifier, cov3D_precomp,
+                         viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, None, dL_dout_depth,
+                         dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R, binningBuffer,
+                         imageBuffer, debug)
+    return g[0], g[1], g[3], g[4], g[5], g[6], g[7], g[8]
+
+
+def rasterize_gaussians_backward_semantic(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
+                                          cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                          dL_dout_semantic, dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh,
+                                          degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA_semantic (rasterize_points.cu:340-432) -> 9 tensors
+    (dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    return _backward_common(True, background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
+                            cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic,
+                            dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
+                            binningBuffer, imageBuffer, debug)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (rasterize_points.cu:217-236) -> bool[P]."""
+    _require_gpu(means3D)
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        with torch.cuda.device(dev):
+            m3, vm, pm = (_prep(x, dev) for x in (means3D, viewmatrix, projmatrix))
+            rc = _lib.hsr_mark_visible(P, _ptr(m3), _ptr(vm), _ptr(pm), present.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream)
+            if rc < 0:
+                _fail(rc, "mark_visible")
+    return present
+
+
+def state_layout(P, width, height, num_rendered):
+    """Byte offsets of the fields inside the three opaque state buffers (parity tests / debugging)."""
+    lay = _StateLayout()
+    rc = _lib.hsr_get_state_layout(int(P), int(width), int(height), int(num_rendered), C.byref(lay))
+    if rc < 0:
+        _fail(rc, "hsr_get_state_layout")
+    return {n: int(getattr(lay, n)) for n, _ in _StateLayout._fields_}

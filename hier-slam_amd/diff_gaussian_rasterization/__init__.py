@@ -1,0 +1,185 @@
+"""diff_gaussian_rasterization — drop-in Python surface of Hier-SLAM's differentiable Gaussian rasterizer,
+backed by the MI355X-native HIP library (libhsr_rast.so) instead of the reference's CUDA extension.
+
+Same public names, argument names, return tuples and error behaviour as the reference package
+(hierslam-diff-gaussian-rasterization-w-depth/diff_gaussian_rasterization/__init__.py):
+
+    GaussianRasterizationSettings            (:161-173)
+    GaussianRasterizer                       (:175-227)  -> (color, radii, depth, median_depth, final_opacity, mask)
+    GaussianRasterizer_semantic              (:377-430)  -> (color, radii, semantic, depth, median_depth, final_opacity)
+    rasterize_gaussians / rasterize_gaussians_semantic   (:21-42, :231-252)
+
+so `from diff_gaussian_rasterization import GaussianRasterizer as Renderer` in scripts/hierslam.py:53-54,
+utils/recon_helpers.py:2 and utils/eval_helpers.py:21-22 keeps working unchanged.  The number of semantic
+channels K is taken from `semantics_precomp.shape[1]` at run time (the reference bakes NUM_SEMANTIC into the
+build, config.h:18).
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "GaussianRasterizer_semantic",
+           "rasterize_gaussians", "rasterize_gaussians_semantic"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """CPU deep copy of the call arguments, taken before the call in debug mode (reference :17-19)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call(fn, args, debug, dump_name, when):
+    """Runs one _C entry point; in debug mode a failure first dumps the inputs (reference :82-90, :294-301)."""
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_name)
+        print("\nAn error occured in %s. Please forward %s for debugging." % (when, dump_name))
+        raise
+
+
+class _Rasterize(torch.autograd.Function):
+    """One autograd node for both variants.  Inputs (semantic variant):
+    means3D, means2D, sh, colors_precomp, semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, settings;
+    the plain variant passes semantics_precomp=None and gets `mask` in place of `semantic`."""
+
+    @staticmethod
+    def forward(ctx, semantic, means3D, means2D, sh, colors_precomp, semantics_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, rs):
+        common = (opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
+                  rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
+                  rs.debug)
+        if semantic:
+            args = (rs.bg, means3D, colors_precomp, semantics_precomp) + common
+            (num_rendered, color, aux, depth, median_depth, final_opacity, radii, geom, binning, img) = _call(
+                _C.rasterize_gaussians_semantic, args, rs.debug, "snapshot_fw.dump", "forward")
+        else:
+            args = (rs.bg, means3D, colors_precomp) + common
+            (num_rendered, color, depth, median_depth, final_opacity, aux, radii, geom, binning, img) = _call(
+                _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+        ctx.semantic = semantic
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, semantics_precomp if semantic else torch.empty(0), means3D, scales, rotations,
+                              cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        if semantic:
+            return color, radii, aux, depth, median_depth, final_opacity
+        return color, radii, depth, median_depth, final_opacity, aux
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, g2, g3, g4, g5):
+        rs = ctx.raster_settings
+        (colors_precomp, semantics_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
+         img) = ctx.saved_tensors
+        if ctx.semantic:
+            grad_sem, grad_depth, grad_median, grad_opacity = g2, g3, g4, g5
+        else:
+            grad_depth, grad_median, grad_opacity = g2, g3, g4  # g5 = grad of mask: ignored, like the reference (:101)
+            grad_sem = None
+        tail = (sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning, img, rs.debug)
+        head = (rs.bg, means3D, radii, colors_precomp)
+        mid = (scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+               grad_color)
+        if ctx.semantic:
+            args = head + (semantics_precomp,) + mid + (grad_sem, grad_depth, grad_median, grad_opacity) + tail
+            (g_means2D, g_colors, g_sem, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot) = _call(
+                _C.rasterize_gaussians_backward_semantic, args, rs.debug, "snapshot_bw.dump", "backward")
+        else:
+            args = head + mid + (grad_depth, grad_median, grad_opacity) + tail
+            (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot) = _call(
+                _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+            g_sem = None
+        # one gradient per forward input: (semantic flag, means3D, means2D, sh, colors, semantics, opacities,
+        # scales, rotations, cov3Ds_precomp, settings)
+        return (None, g_means3D, g_means2D, g_sh, g_colors, g_sem, g_opac, g_scales, g_rot, g_cov3D, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _Rasterize.apply(False, means3D, means2D, sh, colors_precomp, None, opacities, scales, rotations,
+                            cov3Ds_precomp, raster_settings)
+
+
+def rasterize_gaussians_semantic(means3D, means2D, sh, colors_precomp, semantics_precomp, opacities, scales, rotations,
+                                 cov3Ds_precomp, raster_settings):
+    return _Rasterize.apply(True, means3D, means2D, sh, colors_precomp, semantics_precomp, opacities, scales, rotations,
+                            cov3Ds_precomp, raster_settings)
+
+
+def _empty():
+    return torch.Tensor([])
+
+
+def _check_exclusive(shs, colors_precomp, scales, rotations, cov3D_precomp):
+    # messages kept verbatim from the reference (:195-199), typo included, for callers that match on them
+    if (shs is None) == (colors_precomp is None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    has_sr = scales is not None or rotations is not None
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+
+class _RasterizerBase(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: view-space z > 0.2 (reference :180-189)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+
+class GaussianRasterizer(_RasterizerBase):
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        _check_exclusive(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        e = _empty
+        return rasterize_gaussians(
+            means3D, means2D,
+            e() if shs is None else shs,
+            e() if colors_precomp is None else colors_precomp,
+            opacities,
+            e() if scales is None else scales,
+            e() if rotations is None else rotations,
+            e() if cov3D_precomp is None else cov3D_precomp,
+            self.raster_settings)
+
+
+class GaussianRasterizer_semantic(_RasterizerBase):
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, semantics_precomp=None):
+        _check_exclusive(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        e = _empty
+        return rasterize_gaussians_semantic(
+            means3D, means2D,
+            e() if shs is None else shs,
+            e() if colors_precomp is None else colors_precomp,
+            e() if semantics_precomp is None else semantics_precomp,
+            opacities,
+            e() if scales is None else scales,
+            e() if rotations is None else rotations,
+            e() if cov3D_precomp is None else cov3D_precomp,
+            self.raster_settings)

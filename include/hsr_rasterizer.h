@@ -1,0 +1,148 @@
+/*
+ * hsr_rasterizer.h — C ABI of the MI355X-native differentiable Gaussian rasterizer (libhsr_rast.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of LeeBY68/Hier-SLAM: it replaces the static
+ * C++ interface `CudaRasterizer::Rasterizer` of the reference
+ * (hierslam-diff-gaussian-rasterization-w-depth/cuda_rasterizer/rasterizer.h:24-162), which the
+ * reference's torch glue (rasterize_points.cu:36-432) calls.  Each entry point below names the
+ * reference member it replaces.  Differences from the reference interface, all forced by making it
+ * a plain C ABI and by the MI355X design:
+ *   - `std::function<char*(size_t)>` allocator callbacks (rasterizer.h:37-39, rasterize_points.cu:27-33)
+ *     become `hsr_buffer` descriptors: a caller-owned device allocation plus an optional C `grow`
+ *     callback.  Steady state needs no callback at all (the caller sizes buffers with the
+ *     hsr_required_*_bytes() queries), which keeps the host off the critical path.
+ *   - NUM_SEMANTIC is a compile-time macro in the reference (config.h:18, edit + reinstall per
+ *     dataset); here K is a run-time argument.
+ *   - every launch goes to the `stream` argument (a hipStream_t); the reference launches on the legacy
+ *     default stream (e.g. forward.cu:652).
+ *   - errors are return codes (<0) + hsr_last_error(); the reference throws std::runtime_error
+ *     (rasterizer_impl.cu:509-512, auxiliary.h:166-173).
+ *   - gradient outputs are fully written by the library (no caller zero-fill needed; the reference
+ *     requires torch::zeros, rasterize_points.cu:378-388).
+ * All pointers except `hsr_buffer*` and the host callback are DEVICE pointers to contiguous
+ * fp32 / int32 data laid out exactly as the reference's tensors (AoS [P,3], [P,4], [P,K]; planar
+ * CHW images).  Absent optional inputs are NULL (the reference's `data_ptr()==nullptr` switches,
+ * forward.cu:205, :241).  No torch types appear in this interface.
+ */
+#ifndef HSR_RASTERIZER_H_INCLUDED
+#define HSR_RASTERIZER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSR_OK 0
+#define HSR_ERR_INVALID_ARGUMENT (-1) /* bad shape / NULL where data is required / unsupported combination */
+#define HSR_ERR_BUFFER_TOO_SMALL (-2) /* an hsr_buffer is too small and has no grow callback */
+#define HSR_ERR_HIP (-3)              /* a HIP runtime call failed; text in hsr_last_error() */
+#define HSR_ERR_NO_DEVICE (-4)        /* no gfx950 device / kernels not loadable */
+
+/* grows a device allocation to at least `bytes` and returns its base (NULL on failure).
+ * Replaces std::function<char*(size_t)> (rasterizer.h:37-39); `user` is opaque. */
+typedef char* (*hsr_grow_fn)(size_t bytes, void* user);
+
+/* A caller-owned device scratch/state buffer (the reference's geomBuffer / binningBuffer / imgBuffer,
+ * rasterize_points.cu:287-292).  The library uses `ptr` if `capacity` suffices, else calls `grow`
+ * (if non-NULL) and updates ptr/capacity in place.  Contents are opaque to the caller and must be
+ * handed back unchanged to the matching backward call. */
+typedef struct hsr_buffer {
+    char* ptr;
+    size_t capacity;
+    hsr_grow_fn grow;
+    void* user;
+} hsr_buffer;
+
+/* Sizes of the three state buffers (the reference's required<GeometryState>(P) etc.,
+ * rasterizer_impl.h:66-73).  binning is a function of num_rendered. */
+size_t hsr_required_geometry_bytes(int P);
+size_t hsr_required_image_bytes(int width, int height);
+size_t hsr_required_binning_bytes(int num_rendered);
+
+/* Thread-local text of the last error returned by any hsr_* call on this thread. */
+const char* hsr_last_error(void);
+/* Library / build identification, e.g. "hsr_rast 0.1 gfx950". */
+const char* hsr_version(void);
+
+/* Replaces Rasterizer::markVisible (rasterizer.h:27-32, rasterizer_impl.cu:141-153).
+ * present: device uint8[P] (1 = view-space z > 0.2). */
+int hsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Replaces Rasterizer::forward (rasterizer.h:34-64, rasterizer_impl.cu:198-345).
+ * Outputs: out_color[3,H,W], out_depth/out_median_depth/out_opacity/out_mask[1,H,W], radii int32[P]
+ * (radii may be NULL).  Returns num_rendered (>= 0) or a negative HSR_ERR_*.
+ * D = active SH degree, M = SH coefficients per Gaussian (0 when colors_precomp is given). */
+int hsr_forward(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image,
+                int P, int D, int M, const float* background, int width, int height,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered,
+                float* out_color, float* out_depth, float* out_median_depth, float* out_opacity, float* out_mask,
+                int* radii, int debug, void* stream);
+
+/* Replaces Rasterizer::forward_semantic (rasterizer.h:98-128, rasterizer_impl.cu:460-610).
+ * K = number of semantic channels (semantics_precomp is [P,K], out_semantic is [K,H,W]). */
+int hsr_forward_semantic(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image,
+                         int P, int D, int M, int K, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* semantics_precomp, const float* opacities,
+                         const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                         float tan_fovx, float tan_fovy, int prefiltered,
+                         float* out_color, float* out_semantic, float* out_depth, float* out_median_depth,
+                         float* out_opacity, int* radii, int debug, void* stream);
+
+/* Replaces Rasterizer::backward (rasterizer.h:66-96, rasterizer_impl.cu:349-454).
+ * R = num_rendered returned by the matching hsr_forward; the three buffers are the ones it filled.
+ * dL_dmean2D is [P,3] (z unused), dL_dconic [P,4] (.z unused), dL_dopacity [P], dL_dcolor [P,3],
+ * dL_ddepth [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4].
+ * All are fully overwritten. */
+int hsr_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* campos,
+                 float tan_fovx, float tan_fovy, const int* radii,
+                 const char* geom_buffer, const char* binning_buffer, const char* img_buffer,
+                 const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_median_depth,
+                 const float* dL_dpix_final_opacity,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 int debug, void* stream);
+
+/* Replaces Rasterizer::backward_semantic (rasterizer.h:130-162, rasterizer_impl.cu:614-731).
+ * dL_dpix_semantic is [K,H,W], dL_dsemantics [P,K].  The semantic loss reaches only dL_dsemantics:
+ * the reference's semantic->alpha term reads a scratch buffer it never writes (backward.cu:834,
+ * rasterizer_impl.cu:673-674), i.e. contributes 0; this library reproduces that observed behaviour. */
+int hsr_backward_semantic(int P, int D, int M, int K, int R, const float* background, int width, int height,
+                          const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* semantics_precomp,
+                          const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                          const float* viewmatrix, const float* projmatrix, const float* campos,
+                          float tan_fovx, float tan_fovy, const int* radii,
+                          const char* geom_buffer, const char* binning_buffer, const char* img_buffer,
+                          const float* dL_dpix, const float* dL_dpix_semantic, const float* dL_dpix_depth,
+                          const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity,
+                          float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                          float* dL_dsemantics, float* dL_ddepth,
+                          float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                          int debug, void* stream);
+
+/* Read-only view into the opaque state buffers, for parity tests and debugging only (the reference
+ * keeps the same fields in GeometryState / BinningState / ImageState, rasterizer_impl.h:29-64).
+ * Offsets are in bytes from the start of the respective buffer. */
+typedef struct hsr_state_layout {
+    size_t geom_depths, geom_means2D, geom_conic_opacity, geom_cov3D, geom_rgb, geom_clamped,
+        geom_tiles_touched, geom_point_offsets, geom_radii;
+    size_t bin_keys_unsorted, bin_keys, bin_vals_unsorted, bin_vals;
+    size_t img_ranges, img_final_T, img_n_contrib;
+} hsr_state_layout;
+int hsr_get_state_layout(int P, int width, int height, int num_rendered, hsr_state_layout* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSR_RASTERIZER_H_INCLUDED */

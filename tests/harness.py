@@ -1,0 +1,122 @@
+"""Runs one forward+backward through the public torch API on the GPU and through the oracle on the CPU,
+returning comparable dicts.  Used by the -m gpu parity tests."""
+import numpy as np
+import torch
+
+import oracle_lib as O
+
+
+def _cam_to(cam, dev):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(**{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cam.items()})
+
+
+def variant_kwargs(sc, variant, extra=None):
+    """input sets: 'sr' scales+rotations, 'cov' cov3D_precomp; colours: precomp or 'sh' in extra"""
+    kw = {}
+    if variant == "cov":
+        kw["cov3D_precomp"] = extra["cov3D_precomp"]
+    else:
+        kw["scales"], kw["rotations"] = sc["scales"], sc["rotations"]
+    if extra and "shs" in extra:
+        kw["shs"] = extra["shs"]
+    else:
+        kw["colors_precomp"] = sc["colors_precomp"]
+    return kw
+
+
+def run_gpu(cam, sc, up, semantic=True, variant="sr", extra=None, dev="cuda:0", want_state=True):
+    from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizer_semantic, _C
+    dev = torch.device(dev)
+    camd = _cam_to(cam, dev)
+    kw = variant_kwargs(sc, variant, extra)
+    leaves = {n: v.to(dev).clone().requires_grad_(True) for n, v in kw.items()}
+    means3D = sc["means3D"].to(dev).clone().requires_grad_(True)
+    opac = sc["opacities"].to(dev).clone().requires_grad_(True)
+    means2D = torch.zeros(means3D.shape[0], 3, device=dev, requires_grad=True)
+    P = means3D.shape[0]
+    if semantic:
+        sem = sc["semantics_precomp"].to(dev).clone().requires_grad_(True)
+        outs = GaussianRasterizer_semantic(camd)(means3D=means3D, means2D=means2D, opacities=opac,
+                                                 semantics_precomp=sem, **leaves)
+        color, radii, semantic_map, depth, median, opacity = outs
+        loss = (semantic_map * up["semantic"].to(dev)).sum() if semantic_map.numel() else 0.0
+    else:
+        outs = GaussianRasterizer(camd)(means3D=means3D, means2D=means2D, opacities=opac, **leaves)
+        color, radii, depth, median, opacity, mask = outs
+        loss = 0.0
+    loss = loss + (color * up["color"].to(dev)).sum() + (depth * up["depth"].to(dev)).sum() \
+        + (median * up["median"].to(dev)).sum() + (opacity * up["opacity"].to(dev)).sum()
+    node = color.grad_fn
+    saved = node.saved_tensors if (want_state and P > 0) else None  # freed by backward(): grab first
+    num_rendered = node.num_rendered
+    loss.backward()
+    torch.cuda.synchronize()
+    res = dict(color=color, depth=depth, median_depth=median, opacity=opacity, radii=radii)
+    if semantic:
+        res["semantic"] = semantic_map
+    else:
+        res["mask"] = mask
+    res = {n: v.detach().cpu().numpy() for n, v in res.items()}
+    z = lambda t: (t.grad if t.grad is not None else torch.zeros_like(t)).detach().cpu().numpy()
+    grads = dict(means3D=z(means3D), opacities=z(opac), means2D=z(means2D))
+    for n, v in leaves.items():
+        grads[n] = z(v)
+    if semantic:
+        grads["semantics_precomp"] = z(sem)
+    state = None
+    if want_state and P > 0:
+        R = num_rendered
+        H, W = cam["image_height"], cam["image_width"]
+        lay = _C.state_layout(P, W, H, R)
+        geom, binning, img = saved[-3], saved[-2], saved[-1]
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+
+        def view(buf, off, dtype, count, shape):
+            nbytes = count * torch.tensor([], dtype=dtype).element_size()
+            base = (-buf.data_ptr()) % 256  # the library aligns the carve to 256 B from the real address
+            return buf[base + off: base + off + nbytes].view(dtype).reshape(shape).cpu().numpy()
+        state = dict(
+            num_rendered=R,
+            depths=view(geom, lay["geom_depths"], torch.float32, P, (P,)),
+            means2D=view(geom, lay["geom_means2D"], torch.float32, 2 * P, (P, 2)),
+            conic_opacity=view(geom, lay["geom_conic_opacity"], torch.float32, 4 * P, (P, 4)),
+            cov3D=view(geom, lay["geom_cov3D"], torch.float32, 6 * P, (P, 6)),
+            tiles_touched=view(geom, lay["geom_tiles_touched"], torch.int32, P, (P,)).astype(np.uint32),
+            point_offsets=view(geom, lay["geom_point_offsets"], torch.int32, P, (P,)).astype(np.uint32),
+            keys=view(binning, lay["bin_keys"], torch.int64, R, (R,)).astype(np.uint64) if R else np.zeros(0, np.uint64),
+            vals=view(binning, lay["bin_vals"], torch.int32, R, (R,)).astype(np.uint32) if R else np.zeros(0, np.uint32),
+            ranges=view(img, lay["img_ranges"], torch.int32, 2 * T, (T, 2)).astype(np.uint32),
+            final_T=view(img, lay["img_final_T"], torch.float32, W * H, (W * H,)),
+            n_contrib=view(img, lay["img_n_contrib"], torch.int32, W * H, (W * H,)).astype(np.uint32),
+        )
+    return res, grads, state
+
+
+def run_oracle(cam, sc, up, semantic=True, variant="sr", extra=None, threads=0):
+    kw = variant_kwargs(sc, variant, extra)
+    if semantic:
+        kw["semantics_precomp"] = sc["semantics_precomp"]
+    out, st = O.forward(cam, sc["means3D"], sc["opacities"], threads=threads, **kw)
+    g = {n: (v.numpy() if hasattr(v, "numpy") else v) for n, v in up.items()}
+    if not semantic:
+        g["semantic"] = None
+    gr = O.backward(st, cam, sc["means3D"], g, threads=threads, **kw)
+    grads = dict(means3D=gr["means3D"], opacities=gr["opacities"], means2D=gr["means2D"])
+    for n in kw:
+        if n != "semantics_precomp":
+            grads[n] = gr[n]
+    if semantic:
+        grads["semantics_precomp"] = gr["semantics_precomp"]
+    return out, grads, st
+
+
+def assert_close(name, got, exp, rtol=1e-4, atol=1e-4):
+    """|got - exp| <= atol + rtol * max|exp|  (the north-star tolerance: 1e-4 fp32)."""
+    got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64).reshape(np.asarray(got).shape)
+    if got.size == 0:
+        return 0.0
+    err = float(np.abs(got - exp).max())
+    lim = atol + rtol * float(np.abs(exp).max())
+    assert err <= lim, "%s: max abs err %.3e > %.3e (max|exp| %.3e)" % (name, err, lim, float(np.abs(exp).max()))
+    return err

@@ -1,0 +1,145 @@
+"""-m gpu: the HIP path (through the public torch API and the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): radii, tiles_touched, offsets, sorted keys, values and tile ranges
+BIT-EXACT; images and gradients within 1e-4 (fp32).  n_contrib / median depth depend on hard thresholds
+fed by exp(), whose last-ulp differs between glibc and the GPU: compared with a small mismatch budget."""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from harness import assert_close, run_gpu, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (W, H, P, K, kind, scale_mult, semantic, variant, bg, behind_frac)
+    "replica_tree_k26": (160, 96, 3000, 26, "aniso", 2.0, True, "sr", (0, 0, 0), 0.0),
+    "scannet_tree_k16": (128, 80, 2000, 16, "slam", 3.0, True, "sr", (0, 0, 0), 0.0),
+    "generic_k5_white_bg": (100, 70, 1500, 5, "aniso", 2.5, True, "sr", (1.0, 1.0, 1.0), 0.0),  # ragged W,H + bg term
+    "generic_k40_two_chunks": (96, 64, 1200, 40, "aniso", 2.0, True, "sr", (0, 0, 0), 0.0),
+    "large_tree_k74": (96, 64, 1200, 74, "aniso", 2.0, True, "sr", (0.2, 0.1, 0.3), 0.0),
+    "flat_k102": (80, 48, 800, 102, "slam", 3.0, True, "sr", (0, 0, 0), 0.0),
+    "plain_mask": (144, 96, 2500, 0, "aniso", 2.0, False, "sr", (0, 0, 0), 0.0),
+    "plain_cov3d": (96, 80, 1500, 0, "aniso", 2.0, False, "cov", (0, 0, 0), 0.0),
+    "culled_behind_camera": (96, 64, 1500, 26, "aniso", 2.0, True, "sr", (0, 0, 0), 0.4),
+    "huge_splats": (96, 64, 300, 26, "aniso", 40.0, True, "sr", (0, 0, 0), 0.0),  # splats covering the whole screen
+    "semantic_k0": (64, 48, 500, 0, "aniso", 2.0, True, "sr", (0, 0, 0), 0.0),
+}
+
+
+def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
+    out_g, gr_g, st_g = run_gpu(cam, sc, up, semantic=semantic, variant=variant, extra=extra)
+    out_o, gr_o, st_o = run_oracle(cam, sc, up, semantic=semantic, variant=variant, extra=extra)
+    # ---- integer outputs: bit-exact ----
+    assert np.array_equal(out_g["radii"], out_o["radii"]), "radii"
+    assert st_g["num_rendered"] == out_o["num_rendered"], "num_rendered"
+    assert np.array_equal(st_g["tiles_touched"], st_o.field("tiles_touched")), "tiles_touched"
+    assert np.array_equal(st_g["point_offsets"], st_o.field("point_offsets")), "point_offsets"
+    assert np.array_equal(st_g["keys"], st_o.field("keys")), "sorted keys"
+    assert np.array_equal(st_g["vals"], st_o.field("vals")), "sorted values"
+    assert np.array_equal(st_g["ranges"], st_o.field("ranges")), "tile ranges"
+    vis = out_o["radii"] > 0
+    # per-Gaussian fp32 state feeding integer outputs: identical bits by construction (no contraction)
+    assert np.array_equal(st_g["depths"][vis], st_o.field("depths")[vis]), "depths"
+    assert np.array_equal(st_g["means2D"][vis], st_o.field("means2D")[vis]), "means2D"
+    assert np.array_equal(st_g["conic_opacity"][vis], st_o.field("conic_opacity")[vis]), "conic_opacity"
+    # ---- thresholded integers: budgeted ----
+    npix = out_o["color"].shape[1] * out_o["color"].shape[2]
+    nmis = int((st_g["n_contrib"] != st_o.field("n_contrib")).sum())
+    assert nmis <= max(2, npix // 2000), "n_contrib mismatches: %d" % nmis
+    # ---- images ----
+    names = ["color", "depth", "opacity"] + (["semantic"] if semantic else ["mask"])
+    for n in names:
+        assert_close(n, out_g[n], out_o[n])
+    med_bad = int((np.abs(out_g["median_depth"] - out_o["median_depth"]) > 1e-4).sum())
+    assert med_bad <= max(2, npix // 2000), "median depth outliers: %d" % med_bad
+    assert_close("final_T", st_g["final_T"], st_o.field("final_T"))
+    # ---- gradients ----
+    for n in gr_o:
+        assert n in gr_g, n
+        assert_close("grad " + n, gr_g[n], gr_o[n], rtol=grad_rtol, atol=1e-4)
+    st_o.free()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_parity(name):
+    W, H, P, K, kind, sm, semantic, variant, bg, behind = CASES[name]
+    cam, sc, up = scenes.build(W, H, P, K, seed=11, kind=kind, scale_mult=sm, bg=bg, behind_frac=behind)
+    extra = {"cov3D_precomp": scenes.cov3d_from_scene(sc)} if variant == "cov" else None
+    _compare(cam, sc, up, semantic, variant, extra)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_parity_sh(deg):
+    W, H, P, K = 96, 64, 1000, 16
+    cam, sc, up = scenes.build(W, H, P, K, seed=5, kind="aniso", scale_mult=2.0)
+    cam["sh_degree"] = deg
+    extra = {"shs": scenes.random_sh(P, 16)}
+    _compare(cam, sc, up, True, "sr", extra)
+
+
+def test_no_gaussians():
+    from diff_gaussian_rasterization import GaussianRasterizer_semantic
+    from harness import _cam_to
+    cam, sc, up = scenes.build(64, 48, 0, 26)
+    dev = torch.device("cuda:0")
+    z = lambda *s: torch.zeros(*s, device=dev)
+    outs = GaussianRasterizer_semantic(_cam_to(cam, dev))(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1),
+                                                          colors_precomp=z(0, 3), scales=z(0, 3), rotations=z(0, 4),
+                                                          semantics_precomp=z(0, 26))
+    color, radii, sem, depth, median, opac = outs
+    # reference: P == 0 leaves the zero-filled outputs untouched (rasterize_points.cu:294-295)
+    assert radii.numel() == 0 and float(color.abs().max()) == 0 and float(median.abs().max()) == 0
+    assert sem.shape == (26, 48, 64) and float(sem.abs().max()) == 0
+
+
+def test_all_culled():
+    """every Gaussian behind the camera: num_rendered = 0, empty ranges, median depth stays at its default 15"""
+    cam, sc, up = scenes.build(64, 48, 200, 16, behind_frac=1.0)
+    sc["means3D"][:, 2] = -torch.abs(sc["means3D"][:, 2]) - 1.0  # behind the (untilted-ish) camera for sure
+    out_g, gr_g, st_g = run_gpu(cam, sc, up, semantic=True)
+    out_o, gr_o, st_o = run_oracle(cam, sc, up, semantic=True)
+    if out_o["num_rendered"] == 0:
+        assert st_g["num_rendered"] == 0
+        assert float(np.abs(out_g["median_depth"] - 15.0).max()) == 0
+        assert float(np.abs(out_g["color"]).max()) == 0
+    for n in gr_o:
+        assert_close("grad " + n, gr_g[n], gr_o[n])
+
+
+def test_mark_visible():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from harness import _cam_to
+    import oracle_lib as O
+    import ctypes as C
+    cam, sc, up = scenes.build(64, 48, 3000, 0, behind_frac=0.5)
+    dev = torch.device("cuda:0")
+    vis = GaussianRasterizer(_cam_to(cam, dev)).markVisible(sc["means3D"].to(dev)).cpu().numpy()
+    P = sc["means3D"].shape[0]
+    exp = np.zeros(P, np.uint8)
+    m = np.ascontiguousarray(sc["means3D"].numpy()); v = np.ascontiguousarray(cam["viewmatrix"].numpy()); p = np.ascontiguousarray(cam["projmatrix"].numpy())
+    O.lib().hsro_mark_visible(C.c_int(P), m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p),
+                              exp.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(vis, exp.astype(bool))
+    assert 0 < vis.sum() < P
+
+
+def test_repeatable_and_saved_state_independent():
+    """two forwards before two backwards (legal in torch): each backward must see its own state buffers"""
+    from diff_gaussian_rasterization import GaussianRasterizer_semantic
+    from harness import _cam_to
+    cam, sc, up = scenes.build(96, 64, 1500, 16, seed=3)
+    cam2, sc2, up2 = scenes.build(96, 64, 1500, 16, seed=4)
+    dev = torch.device("cuda:0")
+    def fwd(cam_, sc_):
+        leaf = {n: sc_[n].to(dev).clone().requires_grad_(True) for n in ("means3D", "opacities", "colors_precomp", "scales", "rotations", "semantics_precomp")}
+        outs = GaussianRasterizer_semantic(_cam_to(cam_, dev))(means2D=torch.zeros(1500, 3, device=dev, requires_grad=True), **leaf)
+        return leaf, outs
+    l1, o1 = fwd(cam, sc)
+    l2, o2 = fwd(cam2, sc2)
+    (o1[0] * up["color"].to(dev)).sum().backward()
+    (o2[0] * up2["color"].to(dev)).sum().backward()
+    up_only_color = {n: (v if n == "color" else torch.zeros_like(v)) for n, v in up.items()}
+    _, g1, _ = run_oracle(cam, sc, up_only_color)
+    assert_close("grad means3D (first of two in flight)", l1["means3D"].grad.cpu().numpy(), g1["means3D"])
