@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py — forward+backward renders/s of the MI355X-native Hier-SLAM rasterizer.
+
+One "step" = one GaussianRasterizer_semantic forward + one backward with dense upstream gradients on
+all five differentiable outputs (colour, K semantic logits, depth, median depth, final opacity), on the
+workload BASELINE.json's metric is quoted on: synthetic 1200x680 frame, 500k SLAM-like Gaussians, K=26
+(the reference's default tree, config.h:18).  Inputs are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders a different keyframe
+of the same Gaussian set and the per-Gaussian gradients are summed with one bucketed all-reduce over
+RCCL — the keyframe-parallel mapping step of SURVEY.md §8e.  value = renders of all ranks / max time.
+
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel, timed live with HIP events on the
+launch stream through the library's hsr_profile hooks) and `cpu_baseline` (the oracle on the host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "hier-slam_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(P, V, R, W, H, K, e=0):
+    """Per-stage algorithmic HBM bytes of one render (SURVEY.md §8d / BASELINE.md §2), from measured V, R."""
+    N = W * H
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    bit = max(1, int(np.ceil(np.log2(T)))) if T > 1 else 1
+    if (1 << bit) == T:
+        bit += 1  # getHigherMsb(T) of an exact power of two is log2(T)+1
+    s = -(-(32 + bit) // 8)
+    return {
+        "fwd_preprocess": 44 * P + 8 * P + 52 * V,
+        "fwd_scan": 8 * P,
+        "fwd_duplicate": 20 * P + 12 * R,
+        "fwd_sort": 24 * s * R,
+        "fwd_ranges": 8 * R + 8 * T,
+        "fwd_render": R * (44 + 4 * K) + 4 * N * (K + 8),
+        "bwd_zero": 4 * P * (K + 28),
+        "bwd_render": R * (44 + 4 * K * e) + 4 * N * (K + 8) + 8 * R * (K + 10),
+        "bwd_preprocess": 164 * V + 4 * P,
+    }
+
+
+class _Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 9), ("calls", C.c_uint64 * 9)]
+
+
+def perturbed_w2c(rank):
+    """rank 0: identity; other ranks: a small SE(3) perturbation (a different keyframe of the window)"""
+    w2c = np.eye(4)
+    if rank:
+        a = 0.01 * rank
+        w2c[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        w2c[:3, 3] = [0.01 * rank, -0.005 * rank, 0.0]
+    return w2c
+
+
+def cpu_baseline(args, sc, cam_cpu, up):
+    """the oracle (a plain-C port of the reference's algorithm; the reference has no CPU renderer) on the host cores"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    threads = os.cpu_count() or 1
+    kw = dict(colors_precomp=sc["colors_precomp"], semantics_precomp=sc["semantics_precomp"], scales=sc["scales"],
+              rotations=sc["rotations"])
+    g = {n: v.numpy() for n, v in up.items()}
+    n_done, t0 = 0, time.time()
+    while True:
+        out, st = O.forward(cam_cpu, sc["means3D"], sc["opacities"], threads=threads, **kw)
+        O.backward(st, cam_cpu, sc["means3D"], g, threads=threads, **kw)
+        st.free()
+        n_done += 1
+        el = time.time() - t0
+        if el > args.cpu_seconds or n_done >= 50:
+            break
+    return {"value": n_done / el, "unit": "renders/s", "cores": threads, "kind": "port",
+            "sample": "%d fwd+bwd renders of the same %dx%d / %d Gaussians / K=%d workload by the OpenMP C oracle "
+                      "(oracle/hsr_oracle.c) on all %d host threads" % (n_done, args.width, args.height, args.P, args.K, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--P", type=int, default=500000)
+    ap.add_argument("--K", type=int, default=26)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--height", type=int, default=680)
+    ap.add_argument("--kind", default="slam", choices=["slam", "aniso"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket stages with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer_semantic, _C
+    from hsr_utils.camera import replica_intrinsics, setup_camera_tensors
+    from hsr_utils.parallel import GradientBucket
+    from hsr_utils.synthetic import make_scene, make_upstream_grads
+
+    W, H, K, P = args.width, args.height, args.K, args.P
+    kmat = replica_intrinsics(W, H)
+    cam_cpu = setup_camera_tensors(W, H, kmat, perturbed_w2c(rank))
+    cam = GaussianRasterizationSettings(**{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cam_cpu.items()})
+    sc = make_scene(P, W, H, K, kmat, seed=0, kind=args.kind)  # same Gaussians on every rank (replicated parameters)
+    up = make_upstream_grads(W, H, K, seed=1 + rank)
+    names = ("means3D", "colors_precomp", "semantics_precomp", "opacities", "scales", "rotations")
+    leaf = {n: sc[n].to(dev).requires_grad_(True) for n in names}
+    upd = [up[n].to(dev) for n in ("color", "semantic", "depth", "median", "opacity")]
+    renderer = GaussianRasterizer_semantic(cam)
+    bucket = GradientBucket([leaf[n].shape for n in names], dev) if world > 1 else None
+    info = {}
+
+    def step():
+        means2D = torch.zeros(P, 3, device=dev, requires_grad=True)  # hierslam.py:895 retains this grad for densification
+        color, radii, sem, depth, median, opac = renderer(
+            means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"], colors_precomp=leaf["colors_precomp"],
+            scales=leaf["scales"], rotations=leaf["rotations"], semantics_precomp=leaf["semantics_precomp"])
+        info["R"] = color.grad_fn.num_rendered
+        info["radii"] = radii
+        for n in names:
+            leaf[n].grad = None
+        torch.autograd.backward([color, sem, depth, median, opac], upd)
+        if bucket is not None:
+            bucket.pack([leaf[n].grad for n in names])
+            bucket.all_reduce()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    prof = None
+    if not args.no_profile:
+        _C._lib.hsr_profile_read(None, 1)
+        _C._lib.hsr_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    t1 = time.perf_counter()
+    if not args.no_profile:
+        prof = _Profile()
+        _C._lib.hsr_profile_enable(0)
+        _C._lib.hsr_profile_read(C.byref(prof), 1)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        R = int(info["R"])
+        V = int((info["radii"] > 0).sum().item())
+        ms_per_step = 1e3 * elapsed / args.steps
+        out = {
+            "metric": "fwd+bwd renders/sec @1200x680, 500k Gaussians, 4-level tree; grad max-abs-err vs ref",
+            "value": world * args.steps / elapsed, "unit": "renders/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "semantic fwd+bwd render, %dx%d, P=%d %s Gaussians, K=%d semantic channels, "
+                                   "dense upstream grads on colour/semantic/depth/median/opacity" % (W, H, P, args.kind, K),
+                       "P": P, "visible": V, "num_rendered": R, "width": W, "height": H, "K": K,
+                       "parallelism": "keyframe-parallel x%d, grad all-reduce" % world if world > 1 else "single GPU",
+                       "api": "diff_gaussian_rasterization.GaussianRasterizer_semantic (torch autograd) -> C ABI"},
+        }
+        if prof is not None:
+            alg = algorithmic_bytes(P, V, R, W, H, K)
+            stages = {}
+            for i in range(9):
+                nm = _C._lib.hsr_stage_name(i)
+                nm = nm.decode() if isinstance(nm, bytes) else C.cast(nm, C.c_char_p).value.decode()
+                if prof.calls[i]:
+                    stages[nm] = {"ms": prof.ms[i] / prof.calls[i], "alg_bytes": alg[nm],
+                                  "GBps": alg[nm] / (prof.ms[i] / prof.calls[i] * 1e-3) / 1e9}
+            dom = max(stages, key=lambda n: stages[n]["ms"])
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": stages[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                               "kernel_ms": stages[dom]["ms"], "alg_bytes_per_launch": stages[dom]["alg_bytes"]}
+            out["stages_ms"] = {n: round(v["ms"], 4) for n, v in stages.items()}
+            tot_alg = sum(alg.values())
+            out["whole_render"] = {"alg_bytes": tot_alg, "GBps": tot_alg / (ms_per_step * 1e-3) / 1e9,
+                                   "frac_of_hbm_peak": tot_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "device_ms_sum": round(sum(v["ms"] for v in stages.values()), 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, sc, cam_cpu, up)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

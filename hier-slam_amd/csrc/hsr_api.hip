@@ -12,6 +12,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "../../include/hsr_rasterizer.h"
 #include "hsr_common.h"
 
@@ -63,6 +66,49 @@ int acquire(hsr_buffer* b, size_t need, const char* what, char** out)
 }
 
 thread_local uint32_t* g_pinned = nullptr;
+
+// ---- optional per-stage timing with HIP events (hsr_profile_*) ----
+struct StageEvents {
+    int stage;
+    hipEvent_t start, stop;
+};
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::vector<StageEvents> g_prof_pending;
+std::vector<hipEvent_t> g_prof_free;
+hsr_profile g_prof_acc;
+
+hipEvent_t prof_get_event()
+{
+    if (!g_prof_free.empty()) {
+        hipEvent_t e = g_prof_free.back();
+        g_prof_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+struct StageTimer {
+    int stage;
+    hipStream_t stream;
+    hipEvent_t start = nullptr, stop = nullptr;
+    StageTimer(int st, hipStream_t s) : stage(st), stream(s)
+    {
+        if (!g_prof_on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        start = prof_get_event();
+        stop = prof_get_event();
+        if (start) (void)hipEventRecord(start, stream);
+    }
+    ~StageTimer()
+    {
+        if (!start || !stop) return;
+        (void)hipEventRecord(stop, stream);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_pending.push_back({stage, start, stop});
+    }
+};
 
 int read_counter(const uint32_t* dev, uint32_t* host_out, hipStream_t stream)
 {
@@ -153,9 +199,15 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     pa.focal_x = W / (2.0f * in.tan_fovx);
     pa.radii = radii; pa.prefiltered = in.prefiltered; pa.tiles_x = tiles_x; pa.tiles_y = tiles_y;
 
-    hsr_launch_preprocess(pa, g, stream);
+    {
+        StageTimer tm(HSR_STAGE_FWD_PREPROCESS, stream);
+        hsr_launch_preprocess(pa, g, stream);
+    }
     HSR_LAUNCH_CHECK(in.debug, stream);
-    hsr_launch_scan_block_sums(P, g, stream);
+    {
+        StageTimer tm(HSR_STAGE_FWD_SCAN, stream);
+        hsr_launch_scan_block_sums(P, g, stream);
+    }
     HSR_LAUNCH_CHECK(in.debug, stream);
 
     uint32_t R32 = 0;
@@ -177,15 +229,22 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     uint64_t* emit_k = (passes & 1) ? b.keys_unsorted : b.keys;
     uint32_t* emit_v = (passes & 1) ? b.vals_unsorted : b.vals;
     {
+        StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
         BinState be = b;
         be.keys_unsorted = emit_k;
         be.vals_unsorted = emit_v;
         hsr_launch_duplicate(P, radii, tiles_x, tiles_y, g, be, stream);
     }
     HSR_LAUNCH_CHECK(in.debug, stream);
-    if ((rc = hsr_launch_sort_pairs(b, R, end_bit, stream)) != HSR_OK) return rc;
+    {
+        StageTimer tm(HSR_STAGE_FWD_SORT, stream);
+        if ((rc = hsr_launch_sort_pairs(b, R, end_bit, stream)) != HSR_OK) return rc;
+    }
     HSR_LAUNCH_CHECK(in.debug, stream);
-    if ((rc = hsr_launch_tile_ranges(R, T, b.keys, im.ranges, stream)) != HSR_OK) return rc;
+    {
+        StageTimer tm(HSR_STAGE_FWD_RANGES, stream);
+        if ((rc = hsr_launch_tile_ranges(R, T, b.keys, im.ranges, stream)) != HSR_OK) return rc;
+    }
     HSR_LAUNCH_CHECK(in.debug, stream);
 
     RenderFwdArgs ra;
@@ -199,7 +258,10 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
         hsr_set_error("out_mask is NULL");
         return HSR_ERR_INVALID_ARGUMENT;
     }
-    hsr_launch_render_forward(ra, stream);
+    {
+        StageTimer tm(HSR_STAGE_FWD_RENDER, stream);
+        hsr_launch_render_forward(ra, stream);
+    }
     HSR_LAUNCH_CHECK(in.debug, stream);
     return R;
 }
@@ -216,8 +278,27 @@ struct BwdIn {
         *dL_dscale, *dL_drot;
 };
 
+// the sums the tile kernel accumulates atomically start from zero (the reference relies on the
+// caller's torch::zeros, rasterize_points.cu:378-388)
+int zero_accumulators(const BwdIn& in, int K, hipStream_t stream)
+{
+    StageTimer tm(HSR_STAGE_BWD_ZERO, stream);
+    const size_t P = (size_t)in.P;
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dmean2D, 0, sizeof(float) * 3 * P, stream));
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dconic, 0, sizeof(float) * 4 * P, stream));
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dopacity, 0, sizeof(float) * P, stream));
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dcolor, 0, sizeof(float) * 3 * P, stream));
+    HSR_HIP_CHECK(hipMemsetAsync(in.dL_ddepth, 0, sizeof(float) * P, stream));
+    if (K > 0) HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsemantics, 0, sizeof(float) * (size_t)K * P, stream));
+    // SH coefficients above the active degree (and those of culled Gaussians) receive no gradient
+    if (!in.colors_precomp && in.shs && in.dL_dsh && in.M > 0)
+        HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsh, 0, sizeof(float) * 3 * (size_t)in.M * P, stream));
+    return HSR_OK;
+}
+
 int backward_impl(const BwdIn& in, hipStream_t stream)
 {
+    int rc;
     const int P = in.P, W = in.W, H = in.H;
     if (P < 0 || W <= 0 || H <= 0 || in.R < 0) {
         hsr_set_error("invalid sizes P=%d W=%d H=%d R=%d", P, W, H, in.R);
@@ -254,15 +335,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     const int* radii = in.radii ? in.radii : g.radii;
     const int K = in.semantic ? in.K : 0;
 
-    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dmean2D, 0, sizeof(float) * 3 * (size_t)P, stream));
-    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dconic, 0, sizeof(float) * 4 * (size_t)P, stream));
-    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dopacity, 0, sizeof(float) * (size_t)P, stream));
-    HSR_HIP_CHECK(hipMemsetAsync(in.dL_dcolor, 0, sizeof(float) * 3 * (size_t)P, stream));
-    HSR_HIP_CHECK(hipMemsetAsync(in.dL_ddepth, 0, sizeof(float) * (size_t)P, stream));
-    if (K > 0) HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsemantics, 0, sizeof(float) * (size_t)K * (size_t)P, stream));
-    // SH coefficients above the active degree (and those of culled Gaussians) receive no gradient
-    if (!in.colors_precomp && in.shs && in.dL_dsh && in.M > 0)
-        HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsh, 0, sizeof(float) * 3 * (size_t)in.M * (size_t)P, stream));
+    if ((rc = zero_accumulators(in, K, stream)) != HSR_OK) return rc;
 
     if (in.R > 0) {
         RenderBwdArgs ra;
@@ -274,7 +347,10 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         ra.dL_dpix_median = in.dL_dpix_median; ra.dL_dpix_opacity = in.dL_dpix_opacity;
         ra.dL_dmean2D = in.dL_dmean2D; ra.dL_dconic = in.dL_dconic; ra.dL_dopacity = in.dL_dopacity;
         ra.dL_dcolor = in.dL_dcolor; ra.dL_dsemantics = in.dL_dsemantics; ra.dL_ddepth = in.dL_ddepth;
-        hsr_launch_render_backward(ra, stream);
+        {
+            StageTimer tm(HSR_STAGE_BWD_RENDER, stream);
+            hsr_launch_render_backward(ra, stream);
+        }
         HSR_LAUNCH_CHECK(in.debug, stream);
     }
 
@@ -292,7 +368,10 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         hsr_set_error("shs given without dL_dsh / campos");
         return HSR_ERR_INVALID_ARGUMENT;
     }
-    hsr_launch_preprocess_backward(pb, stream);
+    {
+        StageTimer tm(HSR_STAGE_BWD_PREPROCESS, stream);
+        hsr_launch_preprocess_backward(pb, stream);
+    }
     HSR_LAUNCH_CHECK(in.debug, stream);
     return HSR_OK;
 }
@@ -359,6 +438,38 @@ size_t hsr_required_image_bytes(int width, int height) { return hsr_carve_img(nu
 size_t hsr_required_binning_bytes(int num_rendered) { return hsr_carve_bin(nullptr, num_rendered, nullptr) + 256; }
 
 const char* hsr_last_error(void) { return g_err; }
+
+int hsr_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return HSR_OK;
+}
+
+int hsr_profile_read(hsr_profile* out, int reset)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& pe : g_prof_pending) {
+        HSR_HIP_CHECK(hipEventSynchronize(pe.stop));
+        float ms = 0.f;
+        HSR_HIP_CHECK(hipEventElapsedTime(&ms, pe.start, pe.stop));
+        g_prof_acc.ms[pe.stage] += ms;
+        g_prof_acc.calls[pe.stage] += 1;
+        g_prof_free.push_back(pe.start);
+        g_prof_free.push_back(pe.stop);
+    }
+    g_prof_pending.clear();
+    if (out) *out = g_prof_acc;
+    if (reset) memset(&g_prof_acc, 0, sizeof(g_prof_acc));
+    return HSR_OK;
+}
+
+const char* hsr_stage_name(int stage)
+{
+    static const char* names[HSR_STAGE_COUNT] = {"fwd_preprocess", "fwd_scan", "fwd_duplicate", "fwd_sort", "fwd_ranges",
+                                                 "fwd_render", "bwd_zero", "bwd_render", "bwd_preprocess"};
+    return (stage >= 0 && stage < HSR_STAGE_COUNT) ? names[stage] : "?";
+}
 const char* hsr_version(void) { return "hsr_rast 0.1 gfx950"; }
 
 int hsr_get_state_layout(int P, int width, int height, int num_rendered, hsr_state_layout* out)

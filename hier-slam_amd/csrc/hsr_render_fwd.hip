@@ -7,9 +7,13 @@
 //
 // What is different from the reference, by design for CDNA4:
 //   * every per-splat quantity the blend needs — centre, conic, opacity, colour, depth and the K
-//     semantic features — is staged ONCE per tile batch into LDS with coalesced loads and then read
-//     as wave-uniform broadcasts; the reference gathers colour/depth/semantics from global memory per
-//     pixel per splat (forward.cu:503-508).
+//     semantic features — is staged ONCE per tile batch into LDS and then read as wave-uniform
+//     broadcasts; the reference gathers colour/depth/semantics from global memory per pixel per splat
+//     (forward.cu:503-508).
+//   * the staging is software-pipelined: while a batch is blended out of LDS, the gathers of the next
+//     batch (one splat per lane: its id two batches ahead, its 40-byte record and its 4K-byte feature
+//     row one batch ahead) are already in flight into registers, so the dependent
+//     point_list -> record global round trips hide behind compute instead of serialising the tile.
 //   * a splat that no lane of a wave accepts costs that wave only the alpha test (wave ballot), and a
 //     wave whose 64 pixels are all terminated stops blending while it keeps helping to stage.
 //   * K is a template parameter of the kernel but a run-time argument of the library: known tree
@@ -20,12 +24,16 @@ namespace {
 
 template <int KC>
 struct FwdCfg {
-    // LDS per staged splat: 16 (x,y,cx,cy) + 8 (cz,op) + 16 (r,g,b,depth) + 4 (id) + 4*KP
+    // LDS per staged splat: 16 (x,y,cx,cy) + 8 (cz,op) + 16 (r,g,b,depth) + 4*KP
     static constexpr int KP = (KC + 3) & ~3;
     static constexpr int BATCH = KC <= 32 ? 256 : (KC <= 80 ? 128 : 64);
 };
 
-template <int KC, bool BASE, bool MASK>
+// KC: semantic channels handled by this launch (0 = none).  BASE: also produce colour/depth/median/
+// opacity/final_T/n_contrib.  MASK: non-semantic variant, writes mask = sum(alpha*T).
+// ALIGNED: the launch covers whole feature rows of an even K (c0 == 0, KC == K): rows are 8-byte
+// aligned and are fetched as float2.
+template <int KC, bool BASE, bool MASK, bool ALIGNED>
 __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0)
 {
     constexpr int KP = FwdCfg<KC>::KP;
@@ -33,8 +41,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
     __shared__ float4 s_geo[BATCH];   // x, y, conic.x, conic.y
     __shared__ float2 s_co[BATCH];    // conic.z, opacity
     __shared__ float4 s_col[BATCH];   // r, g, b, depth
-    __shared__ int s_id[BATCH];
-    __shared__ float s_sem[KC > 0 ? BATCH * KP : 1];
+    __shared__ float s_sem[KC > 0 ? BATCH * KP : 4];
     __shared__ int s_wdone[4];
 
     const int tiles_x = (a.W + HSR_TILE_X - 1) / HSR_TILE_X;
@@ -58,6 +65,52 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
     for (int c = 0; c < (KC > 0 ? KC : 1); c++) S[c] = 0.f;
     bool done = !inside;
 
+    // ---- software-pipelined staging registers (lane t <-> splat t of a batch) ----
+    int id_next = 0;           // id of splat t of batch b+1 (loaded during batch b-1)
+    float2 p_xy = {0, 0};      // record of splat t of batch b+1 (loaded during batch b)
+    float4 p_co = {0, 0, 0, 0};
+    float p_r = 0, p_g = 0, p_b = 0, p_d = 0;
+    float p_sem[KC > 0 ? KC : 1];
+#pragma unroll
+    for (int c = 0; c < (KC > 0 ? KC : 1); c++) p_sem[c] = 0.f;
+
+    auto load_id = [&](int start) {
+        const int i = start + t;
+        if (t < BATCH && i < n) id_next = (int)a.point_list[range.x + i];
+    };
+    auto load_record = [&](int start) {
+        const int i = start + t;
+        if (t < BATCH && i < n) {
+            const size_t id = (size_t)id_next;
+            p_xy = a.means2D[id];
+            p_co = a.conic_opacity[id];
+            p_d = a.depths[id];
+            if (BASE) {
+                p_r = a.colors[3 * id];
+                p_g = a.colors[3 * id + 1];
+                p_b = a.colors[3 * id + 2];
+            }
+            if (KC > 0) {
+                if (ALIGNED) {
+                    const float2* row = reinterpret_cast<const float2*>(a.semantics + id * (size_t)KC);
+#pragma unroll
+                    for (int q = 0; q < KC / 2; q++) {
+                        const float2 v = row[q];
+                        p_sem[2 * q] = v.x;
+                        p_sem[2 * q + 1] = v.y;
+                    }
+                } else {
+                    const float* row = a.semantics + id * (size_t)a.K + c0;
+#pragma unroll
+                    for (int c = 0; c < KC; c++) p_sem[c] = (c0 + c < a.K) ? row[c] : 0.f;
+                }
+            }
+        }
+    };
+    load_id(0);
+    load_record(0);
+    load_id(BATCH);
+
     for (int start = 0; start < n; start += BATCH) {
         const bool wave_done = __ballot(!done) == 0ull;
         if ((t & 63) == 0) s_wdone[wv] = wave_done;
@@ -65,28 +118,21 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
         if (s_wdone[0] & s_wdone[1] & s_wdone[2] & s_wdone[3]) break;
         const int cnt = min(BATCH, n - start);
         if (t < cnt) {
-            const int id = (int)a.point_list[range.x + start + t];
-            const float2 xy = a.means2D[id];
-            const float4 co = a.conic_opacity[id];
-            s_id[t] = id;
-            s_geo[t] = make_float4(xy.x, xy.y, co.x, co.y);
-            s_co[t] = make_float2(co.z, co.w);
-            if (BASE)
-                s_col[t] = make_float4(a.colors[3 * (size_t)id], a.colors[3 * (size_t)id + 1], a.colors[3 * (size_t)id + 2],
-                                       a.depths[id]);
-            else
-                s_col[t] = make_float4(0, 0, 0, a.depths[id]);
-        }
-        if (KC > 0) {
-            __syncthreads();
-            // consecutive lanes read consecutive floats of a feature row: coalesced 4*KC-byte segments
-            for (int e = t; e < cnt * KC; e += 256) {
-                const int s = e / KC, c = e - s * KC;
-                const int ch = c0 + c;
-                s_sem[s * KP + c] = ch < a.K ? a.semantics[(size_t)s_id[s] * a.K + ch] : 0.f;
+            s_geo[t] = make_float4(p_xy.x, p_xy.y, p_co.x, p_co.y);
+            s_co[t] = make_float2(p_co.z, p_co.w);
+            s_col[t] = make_float4(p_r, p_g, p_b, p_d);
+            if (KC > 0) {
+                float4* row = reinterpret_cast<float4*>(&s_sem[t * KP]);
+#pragma unroll
+                for (int q = 0; q < KP / 4; q++)
+                    row[q] = make_float4(p_sem[4 * q], 4 * q + 1 < KC ? p_sem[4 * q + 1] : 0.f,
+                                         4 * q + 2 < KC ? p_sem[4 * q + 2] : 0.f, 4 * q + 3 < KC ? p_sem[4 * q + 3] : 0.f);
             }
         }
         __syncthreads();
+        // next batch's gathers go out now and land while this batch is blended
+        load_record(start + BATCH);
+        load_id(start + 2 * BATCH);
         if (wave_done) continue;
 
         for (int j = 0; j < cnt; j++) {
@@ -157,19 +203,19 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
     const dim3 grid(tiles), block(256);
     if (!a.semantic) {
-        render_fwd_kernel<0, true, true><<<grid, block, 0, stream>>>(a, 0);
+        render_fwd_kernel<0, true, true, false><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;
     }
     switch (a.K) {
-    case 0: render_fwd_kernel<0, true, false><<<grid, block, 0, stream>>>(a, 0); break;
-    case 16: render_fwd_kernel<16, true, false><<<grid, block, 0, stream>>>(a, 0); break;   // ScanNet tree
-    case 26: render_fwd_kernel<26, true, false><<<grid, block, 0, stream>>>(a, 0); break;   // Replica tree
-    case 74: render_fwd_kernel<74, true, false><<<grid, block, 0, stream>>>(a, 0); break;   // ScanNet large tree
-    case 102: render_fwd_kernel<102, true, false><<<grid, block, 0, stream>>>(a, 0); break; // Replica flat
+    case 0: render_fwd_kernel<0, true, false, false><<<grid, block, 0, stream>>>(a, 0); break;
+    case 16: render_fwd_kernel<16, true, false, true><<<grid, block, 0, stream>>>(a, 0); break;   // ScanNet tree
+    case 26: render_fwd_kernel<26, true, false, true><<<grid, block, 0, stream>>>(a, 0); break;   // Replica tree
+    case 74: render_fwd_kernel<74, true, false, true><<<grid, block, 0, stream>>>(a, 0); break;   // ScanNet large tree
+    case 102: render_fwd_kernel<102, true, false, true><<<grid, block, 0, stream>>>(a, 0); break; // Replica flat
     default:
         // any other K: 32-channel chunks; the first chunk also produces the base outputs
-        render_fwd_kernel<32, true, false><<<grid, block, 0, stream>>>(a, 0);
-        for (int c0 = 32; c0 < a.K; c0 += 32) render_fwd_kernel<32, false, false><<<grid, block, 0, stream>>>(a, c0);
+        render_fwd_kernel<32, true, false, false><<<grid, block, 0, stream>>>(a, 0);
+        for (int c0 = 32; c0 < a.K; c0 += 32) render_fwd_kernel<32, false, false, false><<<grid, block, 0, stream>>>(a, c0);
         break;
     }
     return HSR_OK;

@@ -7,7 +7,8 @@
 //
 // Structure per 8-bit pass (HBM-bound integer work; no MFMA):
 //   1. hist:    each block counts the digits of its 4096-item tile in LDS -> hist[digit][block]
-//   2. scan:    exclusive scan of the digit-major table (one 1024-thread block)
+//   2. rowscan: one wave per digit scans that digit's per-block counts; the 256-entry scan across
+//               digits is redone by every scatter block in LDS
 //   3. scatter: each WAVE owns a contiguous 1024-item chunk of the tile, processed as 16 rounds of
 //               64 consecutive items.  Equal digits inside a round are found with 8 wave ballots
 //               (64-bit masks, v_cmp + s_and), the rank among them is a popcount of the lower-lane
@@ -37,51 +38,40 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint64_t*
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// in-place exclusive scan of `count` u32 entries by one 1024-thread block
-__global__ void __launch_bounds__(1024) sort_scan_kernel(uint32_t* __restrict__ data, int count)
+// One wave per digit: exclusive scan of that digit's per-block counts in place (row d of the
+// digit-major table) and the digit's total -> totals[d].  The scan ACROSS digits (256 entries) is
+// redone by every scatter block in LDS, which removes a serial whole-table scan from the pass.
+__global__ void __launch_bounds__(64) sort_rowscan_kernel(uint32_t* __restrict__ hist, int nblocks,
+                                                           uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t smem[17];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int per = (count + 1023) / 1024;
-    const int beg = threadIdx.x * per;
-    uint32_t local = 0;
-    for (int i = 0; i < per; i++)
-        if (beg + i < count) local += data[beg + i];
-    uint32_t inc = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) smem[w] = inc;
-    __syncthreads();
-    if (w == 0) {
-        const uint32_t s = lane < 16 ? smem[lane] : 0;
-        uint32_t si = s;
+    const int lane = threadIdx.x;
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 64) {
+        const int j = base + lane;
+        const uint32_t v = j < nblocks ? row[j] : 0u;
+        uint32_t inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(si, o);
-            if (lane >= o) si += t;
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
         }
-        if (lane < 16) smem[lane] = si - s;
+        if (j < nblocks) row[j] = carry + inc - v;
+        carry += __shfl(inc, 63);
     }
-    __syncthreads();
-    uint32_t run = smem[w] + inc - local;
-    for (int i = 0; i < per; i++)
-        if (beg + i < count) {
-            const uint32_t v = data[beg + i];
-            data[beg + i] = run;
-            run += v;
-        }
+    if (lane == 0) totals[blockIdx.x] = carry;
 }
 
 __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64_t* __restrict__ kin,
                                                                     const uint32_t* __restrict__ vin,
                                                                     uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                                     int n, int shift, int nblocks,
-                                                                    const uint32_t* __restrict__ hist_scanned)
+                                                                    const uint32_t* __restrict__ hist_scanned,
+                                                                    const uint32_t* __restrict__ totals)
 {
     __shared__ uint32_t wcnt[4][256];  // per-wave running digit counts, then global bases
+    __shared__ uint32_t dig_base[256]; // exclusive scan of the digit totals
+    __shared__ uint32_t wtot[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 4; i++) wcnt[i][threadIdx.x] = 0;
@@ -119,11 +109,26 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
         __builtin_amdgcn_wave_barrier();
         rank[r] = prior + before;
     }
-    __syncthreads();
+    {
+        // exclusive scan over the 256 digit totals (thread t <-> digit t)
+        const uint32_t tv = totals[threadIdx.x];
+        uint32_t inc = tv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();  // also: all waves finished their ranking rounds
+        uint32_t woff = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) woff += i < w ? wtot[i] : 0u;
+        dig_base[threadIdx.x] = woff + inc - tv;
+    }
     {
         // thread t owns digit t: wave-exclusive offsets + this block's global base for the digit
         const uint32_t c0 = wcnt[0][threadIdx.x], c1 = wcnt[1][threadIdx.x], c2 = wcnt[2][threadIdx.x];
-        const uint32_t g = hist_scanned[(size_t)threadIdx.x * nblocks + blockIdx.x];
+        const uint32_t g = dig_base[threadIdx.x] + hist_scanned[(size_t)threadIdx.x * nblocks + blockIdx.x];
         wcnt[0][threadIdx.x] = g;
         wcnt[1][threadIdx.x] = g + c0;
         wcnt[2][threadIdx.x] = g + c0 + c1;
@@ -147,7 +152,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
 uint32_t hsr_sort_hist_entries(int R)
 {
     const int nblocks = (R + SORT_TILE - 1) / SORT_TILE;
-    return 256u * (uint32_t)(nblocks > 0 ? nblocks : 1);
+    return 256u * (uint32_t)(nblocks > 0 ? nblocks : 1) + 256u;  // per-block counts + 256 digit totals
 }
 
 // Sorts the R pairs on key bits [0, end_bit).  The input must already be in the buffer pair that
@@ -158,6 +163,7 @@ int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, hipStream_t stream)
     if (R <= 0) return HSR_OK;
     const int passes = (end_bit + 7) / 8;
     const int nblocks = (R + SORT_TILE - 1) / SORT_TILE;
+    uint32_t* totals = b.hist + (size_t)256 * nblocks;
     uint64_t* ka = (passes & 1) ? b.keys_unsorted : b.keys;
     uint32_t* va = (passes & 1) ? b.vals_unsorted : b.vals;
     uint64_t* kb = (passes & 1) ? b.keys : b.keys_unsorted;
@@ -165,8 +171,8 @@ int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, hipStream_t stream)
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
         sort_hist_kernel<<<nblocks, SORT_THREADS, 0, stream>>>(ka, R, shift, nblocks, b.hist);
-        sort_scan_kernel<<<1, 1024, 0, stream>>>(b.hist, 256 * nblocks);
-        sort_scatter_kernel<<<nblocks, SORT_THREADS, 0, stream>>>(ka, va, kb, vb, R, shift, nblocks, b.hist);
+        sort_rowscan_kernel<<<256, 64, 0, stream>>>(b.hist, nblocks, totals);
+        sort_scatter_kernel<<<nblocks, SORT_THREADS, 0, stream>>>(ka, va, kb, vb, R, shift, nblocks, b.hist, totals);
         uint64_t* tk = ka; ka = kb; kb = tk;
         uint32_t* tv = va; va = vb; vb = tv;
     }

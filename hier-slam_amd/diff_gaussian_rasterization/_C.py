@@ -68,6 +68,12 @@ def _load():
     lib.hsr_backward_semantic.restype = ci
     lib.hsr_backward_semantic.argtypes = [ci, ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf,
                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.hsr_stage_name.restype = C.c_char_p
+    lib.hsr_stage_name.argtypes = [ci]
+    lib.hsr_profile_enable.restype = ci
+    lib.hsr_profile_enable.argtypes = [ci]
+    lib.hsr_profile_read.restype = ci
+    lib.hsr_profile_read.argtypes = [vp, ci]
     lib.hsr_get_state_layout.restype = ci
     lib.hsr_get_state_layout.argtypes = [ci, ci, ci, ci, C.POINTER(_StateLayout)]
     return lib

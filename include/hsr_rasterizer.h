@@ -142,6 +142,23 @@ typedef struct hsr_state_layout {
 } hsr_state_layout;
 int hsr_get_state_layout(int P, int width, int height, int num_rendered, hsr_state_layout* out);
 
+/* ---- measurement hooks (no counterpart in the reference, which has no profiling: SURVEY.md §5) ----
+ * With profiling enabled every stage launch is bracketed by hipEventRecord on the caller's stream;
+ * hsr_profile_read() waits for the recorded events and returns accumulated device time per stage.
+ * bench.py uses this to obtain the dominant kernel's average duration "live" for the roofline line. */
+enum {
+    HSR_STAGE_FWD_PREPROCESS = 0, HSR_STAGE_FWD_SCAN, HSR_STAGE_FWD_DUPLICATE, HSR_STAGE_FWD_SORT,
+    HSR_STAGE_FWD_RANGES, HSR_STAGE_FWD_RENDER, HSR_STAGE_BWD_ZERO, HSR_STAGE_BWD_RENDER, HSR_STAGE_BWD_PREPROCESS,
+    HSR_STAGE_COUNT
+};
+typedef struct hsr_profile {
+    double ms[HSR_STAGE_COUNT];      /* summed device milliseconds per stage since the last reset */
+    uint64_t calls[HSR_STAGE_COUNT]; /* number of timed launches (a stage may be several kernels) */
+} hsr_profile;
+int hsr_profile_enable(int on);
+int hsr_profile_read(hsr_profile* out, int reset);
+const char* hsr_stage_name(int stage);
+
 #ifdef __cplusplus
 }
 #endif

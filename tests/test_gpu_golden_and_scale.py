@@ -1,0 +1,113 @@
+"""-m gpu: (1) the HIP path against the committed golden fixtures (tests/golden/*.npz; no oracle, no
+/root/reference at run time); (2) BASELINE.json's full sizes through size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from harness import _cam_to, assert_close, run_gpu
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz")))
+def test_hip_matches_golden(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    cam = dict(image_height=int(z["H"]), image_width=int(z["W"]), tanfovx=float(z["tanfovx"]), tanfovy=float(z["tanfovy"]),
+               bg=torch.tensor(z["bg"]), scale_modifier=float(z["scale_modifier"]), viewmatrix=torch.tensor(z["viewmatrix"]),
+               projmatrix=torch.tensor(z["projmatrix"]), sh_degree=int(z["sh_degree"]), campos=torch.tensor(z["campos"]),
+               prefiltered=False, debug=False)
+    semantic = bool(z["semantic"])
+    sc = {n: torch.tensor(z[n]) for n in ("means3D", "opacities", "colors_precomp", "scales", "rotations", "semantics_precomp")}
+    up = dict(color=torch.tensor(z["up_color"]), semantic=torch.tensor(z["up_semantic"]), depth=torch.tensor(z["up_depth"]),
+              median=torch.tensor(z["up_median"]), opacity=torch.tensor(z["up_opacity"]))
+    out, gr, st = run_gpu(cam, sc, up, semantic=semantic)
+    assert st["num_rendered"] == int(z["exp_num_rendered"])
+    assert np.array_equal(out["radii"], z["exp_radii"])
+    for n in ("keys", "vals", "ranges", "tiles_touched"):
+        assert np.array_equal(st[n], z["exp_" + n]), n
+    assert int((st["n_contrib"] != z["exp_n_contrib"]).sum()) <= 2
+    for n in ("color", "depth", "opacity") + (("semantic",) if semantic else ("mask",)):
+        assert_close(n, out[n], z["exp_" + n])
+    assert int((np.abs(out["median_depth"] - z["exp_median_depth"]) > 1e-4).sum()) <= 2
+    for n in ("means3D", "means2D", "opacities", "colors_precomp", "scales", "rotations") + (("semantics_precomp",) if semantic else ()):
+        assert_close("grad " + n, gr[n], z["exp_grad_" + n])
+
+
+def _full_size(P, W, H, K, kind="slam"):
+    from diff_gaussian_rasterization import GaussianRasterizer_semantic, _C
+    from hsr_utils.camera import replica_intrinsics, setup_camera_tensors
+    from hsr_utils.synthetic import make_scene
+    dev = torch.device("cuda:0")
+    kmat = replica_intrinsics(W, H)
+    cam = setup_camera_tensors(W, H, kmat, np.eye(4))
+    sc = make_scene(P, W, H, K, kmat, seed=0, kind=kind)
+    leaf = {n: sc[n].to(dev).requires_grad_(True) for n in ("means3D", "opacities", "colors_precomp", "scales", "rotations",
+                                                            "semantics_precomp")}
+    m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+    outs = GaussianRasterizer_semantic(_cam_to(cam, dev))(means2D=m2, **leaf)
+    return cam, sc, leaf, m2, outs
+
+
+@pytest.mark.parametrize("P,W,H,K", [(500000, 1200, 680, 26), (300000, 1200, 680, 16), (2000000, 1920, 1080, 74)])
+def test_full_size_properties(P, W, H, K):
+    """headline / config-2 / stress sizes: sortedness, range consistency, compositing identities, finiteness"""
+    from diff_gaussian_rasterization import _C
+    cam, sc, leaf, m2, (color, radii, sem, depth, median, opac) = _full_size(P, W, H, K)
+    node = color.grad_fn
+    R = node.num_rendered
+    saved = node.saved_tensors
+    geom, binning, img = saved[-3], saved[-2], saved[-1]
+    lay = _C.state_layout(P, W, H, R)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    b0 = (-binning.data_ptr()) % 256
+    keys = binning[b0 + lay["bin_keys"]: b0 + lay["bin_keys"] + 8 * R].view(torch.int64)
+    vals = binning[b0 + lay["bin_vals"]: b0 + lay["bin_vals"] + 4 * R].view(torch.int32)
+    i0 = (-img.data_ptr()) % 256
+    ranges = img[i0 + lay["img_ranges"]: i0 + lay["img_ranges"] + 8 * T].view(torch.int32).reshape(T, 2).long()
+    g0 = (-geom.data_ptr()) % 256
+    touched = geom[g0 + lay["geom_tiles_touched"]: g0 + lay["geom_tiles_touched"] + 4 * P].view(torch.int32).long()
+    depths = geom[g0 + lay["geom_depths"]: g0 + lay["geom_depths"] + 4 * P].view(torch.float32)
+    # num_rendered = sum of tile counts; keys sorted; key = (tile << 32) | depth bits of its Gaussian
+    assert int(touched.sum()) == R and int((radii > 0).sum()) == int((touched > 0).sum())
+    assert bool((keys[1:] >= keys[:-1]).all())
+    tiles = keys >> 32
+    assert int(tiles.min()) >= 0 and int(tiles.max()) < T
+    assert bool(((keys & 0xFFFFFFFF).int() == depths[vals.long()].view(torch.int32)).all())
+    # ranges partition [0, R) by tile, in order
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert int(lens.sum()) == R and bool((lens >= 0).all())
+    cnt = torch.bincount(tiles, minlength=T)
+    assert bool((cnt == lens).all())
+    nz = lens > 0
+    assert bool((tiles[ranges[nz, 0]] == torch.nonzero(nz).squeeze(1)).all())
+    # every Gaussian appears exactly tiles_touched times
+    assert bool((torch.bincount(vals.long(), minlength=P) == touched).all())
+    # images: finite, opacity in [0, 1), colour bounded by opacity (colours in [0,1))
+    for t in (color, sem, depth, median, opac):
+        assert bool(torch.isfinite(t).all())
+    assert float(opac.min()) >= 0 and float(opac.max()) < 1
+    assert float((color - opac).max()) <= 1e-5
+    # linearity of the backward in the upstream gradient + identities with all-ones upstream
+    ones = [torch.zeros_like(color), torch.ones_like(sem), torch.ones_like(depth), torch.zeros_like(median), torch.zeros_like(opac)]
+    torch.autograd.backward([color, sem, depth, median, opac], ones, inputs=list(leaf.values()) + [m2])
+    tot = float(opac.double().sum())
+    assert abs(float(leaf["semantics_precomp"].grad.double().sum()) - K * tot) <= 2e-4 * K * tot
+    for n, p in leaf.items():
+        assert bool(torch.isfinite(p.grad).all()), n
+    # colour got no upstream gradient
+    assert float(leaf["colors_precomp"].grad.abs().max()) == 0
+
+
+def test_forward_is_deterministic_and_backward_reproducible_within_fp32_noise():
+    cam, sc, up = scenes.build(320, 200, 20000, 26, seed=9, kind="slam", scale_mult=2.0)
+    o1, g1, s1 = run_gpu(cam, sc, up)
+    o2, g2, s2 = run_gpu(cam, sc, up)
+    for n in o1:
+        assert np.array_equal(o1[n], o2[n]), n  # forward: no atomics, bit-reproducible
+    assert np.array_equal(s1["keys"], s2["keys"]) and np.array_equal(s1["vals"], s2["vals"])
+    for n in g1:
+        assert_close("grad " + n, g1[n], g2[n], rtol=1e-5, atol=1e-6)  # fp32 atomics: order-dependent last bits
