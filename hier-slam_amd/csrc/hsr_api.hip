@@ -10,6 +10,7 @@
 // scratch in backward_semantic (rasterizer_impl.cu:673-701) has no counterpart.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -340,6 +341,10 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     if (in.R > 0) {
         RenderBwdArgs ra;
         ra.W = W; ra.H = H; ra.K = K; ra.semantic = in.semantic; ra.P = P;
+        {
+            static const int dbg = getenv("HSR_DEBUG_FLAGS") ? atoi(getenv("HSR_DEBUG_FLAGS")) : 0;
+            ra.debug_flags = dbg;
+        }
         ra.bg = in.background; ra.ranges = im.ranges; ra.point_list = b.vals; ra.means2D = g.means2D;
         ra.conic_opacity = g.conic_opacity; ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb;
         ra.final_T = im.final_T; ra.n_contrib = im.n_contrib;

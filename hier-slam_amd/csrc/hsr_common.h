@@ -114,6 +114,7 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream);
 
 struct RenderBwdArgs {
     int W, H, K, semantic, P;
+    int debug_flags;  // HSR_DEBUG_FLAGS env (timing experiments only): bit0 = drop the gradient atomics
     const float* bg;  // device [3]
     const uint2* ranges;
     const uint32_t* point_list;

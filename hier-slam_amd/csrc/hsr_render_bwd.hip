@@ -14,8 +14,9 @@
 // registers and halves the lane set (v_permlane32_swap, v_permlane16_swap, then DPP row_ror:8 /
 // row_half_mirror / quad_perm), so N values cost ~2.4 N instructions instead of 6 N and end up one
 // per lane (lane l holds the total of value bitrev6(l)).  One global_atomic_add_f32 wave-instruction
-// per (wave, splat) then carries all 10+K sums.  Waves in which no lane accepts a splat skip it.
-#include "hsr_common.h"
+// per (wave, splat) then carries all 10+K sums.  Waves own 8x8 quadrants and walk compacted
+// per-quadrant lists (hsr_tile_common.h); of the survivors, a splat no lane accepts is skipped.
+#include "hsr_tile_common.h"
 
 namespace {
 
@@ -100,21 +101,22 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
 {
     constexpr int BATCH = 256;
     constexpr int NV = BASE ? 10 + KC : (KC > 0 ? KC : 1);
-    __shared__ float4 s_geo[BATCH];  // x, y, conic.x, conic.y
-    __shared__ float2 s_co[BATCH];   // conic.z, opacity
+    __shared__ float4 s_geo[BATCH];  // x, y, A, B  (pre-scaled conic, hsr_tile_common.h)
+    __shared__ float2 s_co[BATCH];   // C, opacity
     __shared__ float4 s_col[BATCH];  // r, g, b, depth
     __shared__ int s_id[BATCH];
+    __shared__ uint8_t s_list[4][256];
+    __shared__ uint8_t s_lcnt[4][4];
     __shared__ int s_wmax[4];
 
-    const int tiles_x = (a.W + HSR_TILE_X - 1) / HSR_TILE_X;
     const int tile = blockIdx.x;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int px = tx * HSR_TILE_X + (t & 15), py = ty * HSR_TILE_Y + (t >> 4);
-    const bool inside = px < a.W && py < a.H;
+    const TileGeom tg = tile_geom(tile, a.W, a.H, t);
+    const bool inside = tg.inside;
     const size_t N = (size_t)a.W * a.H;
-    const size_t pix_id = (size_t)a.W * py + px;
-    const float pfx = (float)px, pfy = (float)py;
+    const size_t pix_id = (size_t)a.W * tg.py + tg.px;
+    const float pfx = tg.pfx, pfy = tg.pfy;
+    const float tile_x0 = (float)(tg.tx * HSR_TILE_X), tile_y0 = (float)(tg.ty * HSR_TILE_Y);
     const uint2 range = a.ranges[tile];
 
     const float T_final = inside ? a.final_T[pix_id] : 0.f;
@@ -147,7 +149,8 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
             if (c0 + c < a.K) dsem[c] = a.dL_dpix_sem[(size_t)(c0 + c) * N + pix_id];
     }
     const float bg_dot = BASE ? a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2 : 0.f;
-    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+    // d(pixel)/d(ndc) = 0.5*W, 0.5*H (backward.cu:550-551); 1/log2(e) undoes the conic pre-scale
+    const float kx = (0.5f * a.W) / HSR_LOG2E, ky = (0.5f * a.H) / HSR_LOG2E;
 
     float acc0 = 0, acc1 = 0, acc2 = 0, accd = 0, acco = 0;
     float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_depth = 0, last_op = 0;
@@ -197,85 +200,97 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
         __syncthreads();
+        uint32_t qmask = 0u;
         if (t < cnt) {
-            // j = 0 is the farthest entry of this batch (list position hi-1), like the reference's
+            // slot 0 is the farthest entry of this batch (list position hi-1), like the reference's
             // reverse staging (backward.cu:562, :771)
+            qmask = quadrant_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
             s_id[t] = id_cur;
-            s_geo[t] = make_float4(p_xy.x, p_xy.y, p_co.x, p_co.y);
-            s_co[t] = make_float2(p_co.z, p_co.w);
+            s_geo[t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
+            s_co[t] = make_float2((-0.5f * HSR_LOG2E) * p_co.z, p_co.w);
             if (BASE) s_col[t] = make_float4(p_r, p_g, p_b, p_d);
         }
+        publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
         load_record(hi - BATCH);
         load_id(hi - 2 * BATCH);
         if (hi - cnt >= wmax) continue;  // this wave's pixels all stopped in front of this batch
 
-        for (int j = 0; j < cnt; j++) {
-            const int pos = hi - 1 - j;  // 0-based list position == reference `contributor` after decrement
-            const float4 g = s_geo[j];
-            const float2 co = s_co[j];
-            const float dx = g.x - pfx, dy = g.y - pfy;
-            const float power = -0.5f * (g.z * dx * dx + co.x * dy * dy) - g.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, co.y * G);
-            const bool active = pos < last_contributor && power <= 0.0f && alpha >= 1.0f / 255.0f;
-            if (__ballot(active) == 0ull) continue;
+        for (int seg = 0; seg < 4; seg++) {
+            const int m = s_lcnt[wv][seg];
+            for (int k = 0; k < m; k++) {
+                const int j = s_list[wv][seg * 64 + k];
+                const int pos = hi - 1 - j;  // 0-based list position == reference `contributor` after decrement
+                const float4 g = s_geo[j];
+                const float2 co = s_co[j];
+                const float dx = g.x - pfx, dy = g.y - pfy;
+                const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
+                const float power2 = fmaf(co.x, dyy, fmaf(g.w, dxy, g.z * dxx));  // log2(G)
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float alpha = fminf(0.99f, co.y * G);
+                const bool active = pos < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+                if (__ballot(active) == 0ull) continue;
 
-            // one v_rcp_f32 (1 ulp) instead of the reference's two IEEE divisions by (1 - alpha)
-            // (backward.cu:594, :644): well inside the 1e-4 bar, ~20 instructions per pair cheaper
-            const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
-            const float test_T = T * inv_one_m_a;
-            const float w = active ? alpha * test_T : 0.f;
-            float v[NV];
-            if (BASE) {
-                const float4 cd = s_col[j];
-                float dL_dalpha = 0.f;
-                // colour channels (backward.cu:604-617)
-                const float a0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                const float a1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                const float a2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                dL_dalpha += (cd.x - a0) * dpx0;
-                dL_dalpha += (cd.y - a1) * dpx1;
-                dL_dalpha += (cd.z - a2) * dpx2;
-                v[6] = w * dpx0;
-                v[7] = w * dpx1;
-                v[8] = w * dpx2;
-                // depth (+ median-depth gradient at the T = 0.5 crossing, backward.cu:618-626)
-                const float ad = last_alpha * last_depth + (1.f - last_alpha) * accd;
-                dL_dalpha += (cd.w - ad) * dpd;
-                v[9] = w * dpd + ((active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f);
-                // final opacity as a channel of ones (backward.cu:628-632)
-                const float ao = last_alpha * last_op + (1.f - last_alpha) * acco;
-                dL_dalpha += (1.f - ao) * dpo;
-                dL_dalpha *= test_T;
-                dL_dalpha += (-T_final * inv_one_m_a) * bg_dot;
-                if (!active) dL_dalpha = 0.f;
-                const float dL_dG = co.y * dL_dalpha;
-                const float Gs = active ? G : 0.f;  // exp(power>0) may be inf on rejected lanes: keep it out of the sums
-                const float gdx = Gs * dx, gdy = Gs * dy;
-                const float dG_ddelx = -gdx * g.z - gdy * g.w;
-                const float dG_ddely = -gdy * co.x - gdx * g.w;
-                v[0] = dL_dG * dG_ddelx * ddelx_dx;
-                v[1] = dL_dG * dG_ddely * ddely_dy;
-                v[2] = -0.5f * gdx * dx * dL_dG;
-                v[3] = -0.5f * gdx * dy * dL_dG;
-                v[4] = -0.5f * gdy * dy * dL_dG;
-                v[5] = w * dpo + Gs * dL_dalpha;
-                if (active) {
-                    acc0 = a0; acc1 = a1; acc2 = a2; accd = ad; acco = ao;
-                    lc0 = cd.x; lc1 = cd.y; lc2 = cd.z; last_depth = cd.w; last_op = 1.f;
-                    last_alpha = alpha;
+                // one v_rcp_f32 (1 ulp) instead of the reference's two IEEE divisions by (1 - alpha)
+                // (backward.cu:594, :644): well inside the 1e-4 bar, ~20 instructions per pair cheaper
+                const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float test_T = T * inv_one_m_a;
+                const float w = active ? alpha * test_T : 0.f;
+                float v[NV];
+                if (BASE) {
+                    const float4 cd = s_col[j];
+                    float dL_dalpha = 0.f;
+                    // colour channels (backward.cu:604-617)
+                    const float a0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                    const float a1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                    const float a2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                    dL_dalpha += (cd.x - a0) * dpx0;
+                    dL_dalpha += (cd.y - a1) * dpx1;
+                    dL_dalpha += (cd.z - a2) * dpx2;
+                    v[6] = w * dpx0;
+                    v[7] = w * dpx1;
+                    v[8] = w * dpx2;
+                    // depth (+ median-depth gradient at the T = 0.5 crossing, backward.cu:618-626)
+                    const float ad = last_alpha * last_depth + (1.f - last_alpha) * accd;
+                    dL_dalpha += (cd.w - ad) * dpd;
+                    v[9] = w * dpd + ((active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f);
+                    // final opacity as a channel of ones (backward.cu:628-632)
+                    const float ao = last_alpha * last_op + (1.f - last_alpha) * acco;
+                    dL_dalpha += (1.f - ao) * dpo;
+                    dL_dalpha *= test_T;
+                    dL_dalpha += (-T_final * inv_one_m_a) * bg_dot;
+                    // rejected lanes contribute nothing (and exp2 of a positive power may be inf)
+                    const float Gs = active ? G : 0.f;
+                    const float gda = Gs * dL_dalpha;        // G * dL_dalpha
+                    const float q = co.y * gda;              // G * dL_dG
+                    // dG/ddelx = -G*(dx*cx + dy*cy) = G*(2A*dx + B*dy)/log2e  (backward.cu:648-651)
+                    v[0] = q * fmaf(2.0f * g.z, dx, g.w * dy) * kx;
+                    v[1] = q * fmaf(2.0f * co.x, dy, g.w * dx) * ky;
+                    const float hq = -0.5f * q;
+                    v[2] = hq * dxx;
+                    v[3] = hq * dxy;
+                    v[4] = hq * dyy;
+                    v[5] = fmaf(w, dpo, gda);
+                    if (active) {
+                        acc0 = a0; acc1 = a1; acc2 = a2; accd = ad; acco = ao;
+                        lc0 = cd.x; lc1 = cd.y; lc2 = cd.z; last_depth = cd.w; last_op = 1.f;
+                        last_alpha = alpha;
+                    }
+#pragma unroll
+                    for (int c = 0; c < KC; c++) v[10 + c] = w * dsem[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < KC; c++) v[c] = w * dsem[c];
                 }
-#pragma unroll
-                for (int c = 0; c < KC; c++) v[10 + c] = w * dsem[c];
-            } else {
-#pragma unroll
-                for (int c = 0; c < KC; c++) v[c] = w * dsem[c];
-            }
-            if (active) T = test_T;
+                if (active) T = test_T;
 
-            const float total = wave_reduce_transpose<NV>(v, lane);
-            if (tgt_base) atomicAdd(tgt_base + (size_t)s_id[j] * tgt_stride, total);
+                const float total = wave_reduce_transpose<NV>(v, lane);
+                if (a.debug_flags & 1) {
+                    asm volatile("" ::"v"(total));  // timing experiment: keep the sum alive, drop the atomic
+                } else if (tgt_base) {
+                    atomicAdd(tgt_base + (size_t)s_id[j] * tgt_stride, total);
+                }
+            }
         }
     }
 }

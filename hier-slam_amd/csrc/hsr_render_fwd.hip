@@ -14,11 +14,15 @@
 //     batch (one splat per lane: its id two batches ahead, its 40-byte record and its 4K-byte feature
 //     row one batch ahead) are already in flight into registers, so the dependent
 //     point_list -> record global round trips hide behind compute instead of serialising the tile.
-//   * a splat that no lane of a wave accepts costs that wave only the alpha test (wave ballot), and a
-//     wave whose 64 pixels are all terminated stops blending while it keeps helping to stage.
+//   * each wave owns an 8x8 quadrant and walks a compacted per-quadrant list built at staging time from
+//     the splats' alpha>=1/255 bounding boxes (hsr_tile_common.h), so splats that cannot touch the
+//     quadrant cost it nothing; of the survivors, one that no lane accepts costs only the alpha test
+//     (wave ballot).  A wave whose 64 pixels are all terminated stops blending but keeps staging.
+//   * records are staged pre-scaled (log2(e) and the -0.5 folded into the conic) so alpha costs one
+//     v_exp_f32 and a handful of FMAs: the kernel is VALU-issue bound, not HBM bound.
 //   * K is a template parameter of the kernel but a run-time argument of the library: known tree
 //     sizes get one fused launch, any other K is rendered in 32-channel chunks.
-#include "hsr_common.h"
+#include "hsr_tile_common.h"
 
 namespace {
 
@@ -38,21 +42,22 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
 {
     constexpr int KP = FwdCfg<KC>::KP;
     constexpr int BATCH = FwdCfg<KC>::BATCH;
-    __shared__ float4 s_geo[BATCH];   // x, y, conic.x, conic.y
-    __shared__ float2 s_co[BATCH];    // conic.z, opacity
+    __shared__ float4 s_geo[BATCH];   // x, y, A, B   (pre-scaled conic, see hsr_tile_common.h)
+    __shared__ float2 s_co[BATCH];    // C, opacity
     __shared__ float4 s_col[BATCH];   // r, g, b, depth
     __shared__ float s_sem[KC > 0 ? BATCH * KP : 4];
+    __shared__ uint8_t s_list[4][256];
+    __shared__ uint8_t s_lcnt[4][4];
     __shared__ int s_wdone[4];
 
-    const int tiles_x = (a.W + HSR_TILE_X - 1) / HSR_TILE_X;
     const int tile = blockIdx.x;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int t = threadIdx.x, wv = t >> 6;
-    const int px = tx * HSR_TILE_X + (t & 15), py = ty * HSR_TILE_Y + (t >> 4);
-    const bool inside = px < a.W && py < a.H;
+    const TileGeom tg = tile_geom(tile, a.W, a.H, t);
+    const bool inside = tg.inside;
     const size_t N = (size_t)a.W * a.H;
-    const size_t pix_id = (size_t)a.W * py + px;
-    const float pfx = (float)px, pfy = (float)py;
+    const size_t pix_id = (size_t)a.W * tg.py + tg.px;
+    const float pfx = tg.pfx, pfy = tg.pfy;
+    const float tile_x0 = (float)(tg.tx * HSR_TILE_X), tile_y0 = (float)(tg.ty * HSR_TILE_Y);
 
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
@@ -117,9 +122,11 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
         __syncthreads();  // also: everyone has finished reading the previous batch
         if (s_wdone[0] & s_wdone[1] & s_wdone[2] & s_wdone[3]) break;
         const int cnt = min(BATCH, n - start);
+        uint32_t qmask = 0u;
         if (t < cnt) {
-            s_geo[t] = make_float4(p_xy.x, p_xy.y, p_co.x, p_co.y);
-            s_co[t] = make_float2(p_co.z, p_co.w);
+            qmask = quadrant_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
+            s_geo[t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
+            s_co[t] = make_float2((-0.5f * HSR_LOG2E) * p_co.z, p_co.w);
             s_col[t] = make_float4(p_r, p_g, p_b, p_d);
             if (KC > 0) {
                 float4* row = reinterpret_cast<float4*>(&s_sem[t * KP]);
@@ -129,49 +136,55 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
                                          4 * q + 2 < KC ? p_sem[4 * q + 2] : 0.f, 4 * q + 3 < KC ? p_sem[4 * q + 3] : 0.f);
             }
         }
+        publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
         // next batch's gathers go out now and land while this batch is blended
         load_record(start + BATCH);
         load_id(start + 2 * BATCH);
         if (wave_done) continue;
 
-        for (int j = 0; j < cnt; j++) {
-            const float4 g = s_geo[j];
-            const float2 co = s_co[j];
-            const float dx = g.x - pfx, dy = g.y - pfy;
-            const float power = -0.5f * (g.z * dx * dx + co.x * dy * dy) - g.w * dx * dy;
-            const float alpha = fminf(0.99f, co.y * __expf(power));
-            bool contrib = !done && power <= 0.0f && alpha >= 1.0f / 255.0f;
-            const float test_T = T * (1.0f - alpha);
-            if (contrib && test_T < 0.0001f) {
-                done = true;
-                contrib = false;
-            }
-            if (__ballot(contrib) == 0ull) continue;
-            const float w = contrib ? alpha * T : 0.f;
-            const float4 cd = s_col[j];
-            if (BASE) {
-                C0 = fmaf(cd.x, w, C0);
-                C1 = fmaf(cd.y, w, C1);
-                C2 = fmaf(cd.z, w, C2);
-                Dd = fmaf(cd.w, w, Dd);
-                if (MASK) Mm += w;
-                if (contrib && T > 0.5f && test_T < 0.5f) median_D = cd.w;
-            }
-            if (KC > 0) {
-                const float4* row = reinterpret_cast<const float4*>(&s_sem[j * KP]);
-#pragma unroll
-                for (int q = 0; q < KP / 4; q++) {
-                    const float4 f = row[q];
-                    if (4 * q + 0 < KC) S[4 * q + 0] = fmaf(f.x, w, S[4 * q + 0]);
-                    if (4 * q + 1 < KC) S[4 * q + 1] = fmaf(f.y, w, S[4 * q + 1]);
-                    if (4 * q + 2 < KC) S[4 * q + 2] = fmaf(f.z, w, S[4 * q + 2]);
-                    if (4 * q + 3 < KC) S[4 * q + 3] = fmaf(f.w, w, S[4 * q + 3]);
+        // this wave's compacted list: four segments (one per staging wave), slot order preserved
+        for (int seg = 0; seg < 4; seg++) {
+            const int m = s_lcnt[wv][seg];
+            for (int k = 0; k < m; k++) {
+                const int j = s_list[wv][seg * 64 + k];
+                const float4 g = s_geo[j];
+                const float2 co = s_co[j];
+                const float dx = g.x - pfx, dy = g.y - pfy;
+                const float power2 = fmaf(co.x, dy * dy, fmaf(g.w, dx * dy, g.z * (dx * dx)));  // log2(G)
+                const float alpha = fminf(0.99f, co.y * __builtin_amdgcn_exp2f(power2));
+                bool contrib = !done && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+                const float test_T = T * (1.0f - alpha);
+                if (contrib && test_T < 0.0001f) {
+                    done = true;
+                    contrib = false;
                 }
-            }
-            if (contrib) {
-                T = test_T;
-                last_contributor = (uint32_t)(start + j + 1);
+                if (__ballot(contrib) == 0ull) continue;
+                const float w = contrib ? alpha * T : 0.f;
+                const float4 cd = s_col[j];
+                if (BASE) {
+                    C0 = fmaf(cd.x, w, C0);
+                    C1 = fmaf(cd.y, w, C1);
+                    C2 = fmaf(cd.z, w, C2);
+                    Dd = fmaf(cd.w, w, Dd);
+                    if (MASK) Mm += w;
+                    if (contrib && T > 0.5f && test_T < 0.5f) median_D = cd.w;
+                }
+                if (KC > 0) {
+                    const float4* row = reinterpret_cast<const float4*>(&s_sem[j * KP]);
+#pragma unroll
+                    for (int q = 0; q < KP / 4; q++) {
+                        const float4 f = row[q];
+                        if (4 * q + 0 < KC) S[4 * q + 0] = fmaf(f.x, w, S[4 * q + 0]);
+                        if (4 * q + 1 < KC) S[4 * q + 1] = fmaf(f.y, w, S[4 * q + 1]);
+                        if (4 * q + 2 < KC) S[4 * q + 2] = fmaf(f.z, w, S[4 * q + 2]);
+                        if (4 * q + 3 < KC) S[4 * q + 3] = fmaf(f.w, w, S[4 * q + 3]);
+                    }
+                }
+                if (contrib) {
+                    T = test_T;
+                    last_contributor = (uint32_t)(start + j + 1);
+                }
             }
         }
     }

@@ -1,0 +1,90 @@
+// hsr_tile_common.h — pieces shared by the forward and backward 16x16-tile kernels (gfx950, wave64).
+//
+// Tile decomposition: one 256-thread workgroup per 16x16 tile (the reference's BLOCK_X x BLOCK_Y,
+// config.h:16-17, which also fixes the binning keys), four waves, each wave owning one 8x8 QUADRANT
+// of the tile (lane l -> pixel (l & 7, l >> 3) of the quadrant).  A compact wave footprint matters
+// because every per-splat decision ("does any of my 64 pixels see this splat?") is taken per wave.
+//
+// Staged splat record (LDS, one per list entry of the current batch), pre-scaled so that the blend loop
+// evaluates alpha with as few VALU instructions as possible — these kernels are VALU-issue bound:
+//     geo  = { x, y, A, B }      A = -0.5*log2(e)*conic.x     B = -log2(e)*conic.y
+//     co   = { C, opacity }      C = -0.5*log2(e)*conic.z
+//   => log2(G) = A*dx*dx + B*dx*dy + C*dy*dy,  G = exp2(.) (one v_exp_f32),  alpha = min(0.99, opacity*G)
+// which is the reference's power = -0.5*(cx*dx^2 + cz*dy^2) - cy*dx*dy, alpha = min(0.99, o*exp(power))
+// (forward.cu:484-492) up to fp32 rounding (tolerance-tested; thresholds are applied to the same alpha).
+//
+// Per-wave culling: at staging time the lane that owns a splat also computes a conservative bounding
+// box of the region where alpha can reach 1/255 (an ellipse: A*dx^2 + B*dx*dy + C*dy^2 >= -log2(255*o))
+// and, for each quadrant, whether the box touches it.  A wave ballot turns that into a compacted,
+// order-preserving list of batch slots per quadrant, so the blend loop of a wave only ever visits splats
+// that can touch its 64 pixels.  The exact per-pixel tests still run on the survivors, so results do not
+// depend on the box (it only has to be conservative).
+#pragma once
+#include "hsr_common.h"
+
+#define HSR_LOG2E 1.4426950408889634f
+
+struct TileGeom {
+    int tx, ty;        // tile coordinates
+    int px, py;        // this lane's pixel
+    bool inside;
+    float pfx, pfy;
+    float qx0, qy0;    // first pixel of this wave's quadrant (float)
+};
+
+__device__ __forceinline__ TileGeom tile_geom(int tile, int W, int H, int t)
+{
+    TileGeom g;
+    const int tiles_x = (W + HSR_TILE_X - 1) / HSR_TILE_X;
+    g.tx = tile % tiles_x;
+    g.ty = tile / tiles_x;
+    const int wv = t >> 6, l = t & 63;
+    const int qx = (wv & 1) * 8, qy = (wv >> 1) * 8;
+    g.px = g.tx * HSR_TILE_X + qx + (l & 7);
+    g.py = g.ty * HSR_TILE_Y + qy + (l >> 3);
+    g.inside = g.px < W && g.py < H;
+    g.pfx = (float)g.px;
+    g.pfy = (float)g.py;
+    g.qx0 = (float)(g.tx * HSR_TILE_X + qx);
+    g.qy0 = (float)(g.ty * HSR_TILE_Y + qy);
+    return g;
+}
+
+// 4-bit mask of the tile's quadrants (bit q = wave q) that the splat's alpha >= 1/255 region can touch.
+// xy: centre, conic (cx, cy, cz), opacity.  Conservative: boxes are inflated by a relative 1e-3 + 0.05 px.
+__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float cx, float cy, float cz, float opacity, float tile_x0,
+                                                  float tile_y0)
+{
+    // alpha >= 1/255  <=>  power >= -ln(255*o) =: -tau;  no pixel qualifies when 255*o < 1
+    const float t255 = 255.0f * opacity;
+    if (!(t255 >= 1.0f)) return 0u;
+    const float tau2 = 2.0f * __logf(t255) * 1.001f + 1e-4f;  // 2*tau, inflated
+    const float det = cx * cz - cy * cy;
+    // degenerate / non-positive-definite conic: do not cull
+    if (!(det > 0.0f) || !(cx > 0.0f) || !(cz > 0.0f)) return 0xFu;
+    const float inv_det = 1.0f / det;
+    const float hx = sqrtf(tau2 * cz * inv_det) * 1.001f + 0.05f;
+    const float hy = sqrtf(tau2 * cx * inv_det) * 1.001f + 0.05f;
+    const float x0 = x - hx - tile_x0, x1 = x + hx - tile_x0;  // tile-relative extent
+    const float y0 = y - hy - tile_y0, y1 = y + hy - tile_y0;
+    // quadrant pixel centres: [0,7] and [8,15] on each axis
+    const bool xl = x0 <= 7.0f && x1 >= 0.0f, xr = x0 <= 15.0f && x1 >= 8.0f;
+    const bool yt = y0 <= 7.0f && y1 >= 0.0f, yb = y0 <= 15.0f && y1 >= 8.0f;
+    return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
+}
+
+// Builds the per-quadrant compacted slot lists for one staged batch.  Lane t staged slot t (or nothing
+// when t >= cnt).  s_list[q][sw*64 + k] = k-th slot staged by wave `sw` that touches quadrant q (order
+// preserved); s_lcnt[q][sw] = how many.  Call between the record stores and the barrier before blending.
+__device__ __forceinline__ void publish_quadrant_lists(uint32_t qmask, int t, uint8_t (*s_list)[256], uint8_t (*s_lcnt)[4])
+{
+    const int lane = t & 63, sw = t >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const bool on = (qmask >> q) & 1u;
+        const uint64_t m = __ballot(on);
+        if (on) s_list[q][sw * 64 + __popcll(m & lt)] = (uint8_t)t;
+        if (lane == 0) s_lcnt[q][sw] = (uint8_t)__popcll(m);
+    }
+}
