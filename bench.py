@@ -69,7 +69,8 @@ def cpu_baseline(args, sc, cam_cpu, up):
     """the oracle (a plain-C port of the reference's algorithm; the reference has no CPU renderer) on the host cores"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    threads = os.cpu_count() or 1
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(threads, int(os.environ.get("HSR_CPU_THREADS", "64")))  # OpenMP scaling of the oracle flattens out
     kw = dict(colors_precomp=sc["colors_precomp"], semantics_precomp=sc["semantics_precomp"], scales=sc["scales"],
               rotations=sc["rotations"])
     g = {n: v.numpy() for n, v in up.items()}
@@ -201,6 +202,16 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": stages[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
                                "kernel_ms": stages[dom]["ms"], "alg_bytes_per_launch": stages[dom]["alg_bytes"]}
+            # HBM traffic of the dominant kernel from the PMC passes of tools/profile_gpu.sh (committed under
+            # profiles/; counters cannot be read from inside this process), when it was taken on this workload
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+                wl = tj["workload"]
+                if (wl["P"], wl["width"], wl["height"], wl["K"], wl["kind"]) == (P, W, H, K, args.kind):
+                    out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"].get(dom)
+                    out["roofline"]["traffic_source"] = tj["source"]
+            except Exception:
+                pass
             out["stages_ms"] = {n: round(v["ms"], 4) for n, v in stages.items()}
             tot_alg = sum(alg.values())
             out["whole_render"] = {"alg_bytes": tot_alg, "GBps": tot_alg / (ms_per_step * 1e-3) / 1e9,

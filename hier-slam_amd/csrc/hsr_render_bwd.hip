@@ -12,8 +12,8 @@
 // (pixel, splat) pair (backward.cu:616-663, :828-896).  Here the 10+K per-lane terms of one splat
 // are summed across the 64 lanes of a wave with a *transposing* butterfly: each stage pairs two
 // registers and halves the lane set (v_permlane32_swap, v_permlane16_swap, then DPP row_ror:8 /
-// row_half_mirror / quad_perm), so N values cost ~2.4 N instructions instead of 6 N and end up one
-// per lane (lane l holds the total of value bitrev6(l)).  One global_atomic_add_f32 wave-instruction
+// row_half_mirror / quad_perm), so N values cost ~3 N instructions instead of 6 N and end up one
+// per lane.  One global_atomic_add_f32 wave-instruction
 // per (wave, splat) then carries all 10+K sums.  Waves own 8x8 quadrants and walk compacted
 // per-quadrant lists (hsr_tile_common.h); of the survivors, a splat no lane accepts is skipped.
 #include "hsr_tile_common.h"
@@ -54,8 +54,11 @@ constexpr int DPP_ROW_HALF_MIRROR = 0x141;
 constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm [2,3,0,1]
 constexpr int DPP_QUAD_XOR1 = 0xB1;  // quad_perm [1,0,3,2]
 
-// Sums each of the N per-lane values over the 64 lanes of the wave.  Returns, in lane l, the total of
-// v[bitrev6(l)] (garbage-free zero where bitrev6(l) >= N is not guaranteed: callers mask by index).
+// Sums each of the N per-lane values over the 64 lanes of the wave; lane l returns the total of
+// v[reduce_slot(l)] (don't-care where that index is >= N).  Stage order is chosen by instruction cost on gfx950: the four
+// in-row stages (quad_perm xor 1, xor 2, row_half_mirror, row_ror:8) are full-rate DPP adds and run
+// while there are many registers; the two cross-row stages (v_permlane16_swap, v_permlane32_swap —
+// slower, with hazard wait states) run last on the 3 and 2 registers that are left.
 template <int M>
 __device__ __forceinline__ float elem_or_zero(const float (&x)[M], int i)
 {
@@ -69,23 +72,26 @@ __device__ __forceinline__ float wave_reduce_transpose(const float (&v)[N], int 
     constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
     static_assert((N5 + 1) / 2 == 1, "six stages reduce to one register");
     float a[N1], b[N2], c[N3], d[N4], e[N5];
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 #pragma unroll
-    for (int i = 0; i < N1; i++) a[i] = pair32(v[2 * i], elem_or_zero(v, 2 * i + 1));
+    // row_half_mirror pairs l with 7-l (flips bits 0..2), so it must come first: each later pairing
+    // (xor 1, xor 2, xor 8, xor 16, xor 32) then joins lanes that agree on every earlier select bit
+    for (int i = 0; i < N1; i++) a[i] = pair_dpp<DPP_ROW_HALF_MIRROR>(v[2 * i], elem_or_zero(v, 2 * i + 1), b2);
 #pragma unroll
-    for (int i = 0; i < N2; i++) b[i] = pair16(a[2 * i], elem_or_zero(a, 2 * i + 1));
-    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    for (int i = 0; i < N2; i++) b[i] = pair_dpp<DPP_QUAD_XOR1>(a[2 * i], elem_or_zero(a, 2 * i + 1), b0);
 #pragma unroll
-    for (int i = 0; i < N3; i++) c[i] = pair_dpp<DPP_ROW_ROR8>(b[2 * i], elem_or_zero(b, 2 * i + 1), b3);
+    for (int i = 0; i < N3; i++) c[i] = pair_dpp<DPP_QUAD_XOR2>(b[2 * i], elem_or_zero(b, 2 * i + 1), b1);
 #pragma unroll
-    for (int i = 0; i < N4; i++) d[i] = pair_dpp<DPP_ROW_HALF_MIRROR>(c[2 * i], elem_or_zero(c, 2 * i + 1), b2);
+    for (int i = 0; i < N4; i++) d[i] = pair_dpp<DPP_ROW_ROR8>(c[2 * i], elem_or_zero(c, 2 * i + 1), b3);
 #pragma unroll
-    for (int i = 0; i < N5; i++) e[i] = pair_dpp<DPP_QUAD_XOR2>(d[2 * i], elem_or_zero(d, 2 * i + 1), b1);
-    return pair_dpp<DPP_QUAD_XOR1>(e[0], elem_or_zero(e, 1), b0);
+    for (int i = 0; i < N5; i++) e[i] = pair16(d[2 * i], elem_or_zero(d, 2 * i + 1));
+    return pair32(e[0], elem_or_zero(e, 1));
 }
 
-__device__ __forceinline__ int bitrev6(int l)
+// which value a lane holds after wave_reduce_transpose: select bits in stage order b2, b0, b1, b3, b4, b5
+__device__ __forceinline__ int reduce_slot(int l)
 {
-    return ((l & 1) << 5) | ((l & 2) << 3) | ((l & 4) << 1) | ((l & 8) >> 1) | ((l & 16) >> 3) | ((l & 32) >> 5);
+    return ((l >> 2) & 1) | ((l & 1) << 1) | (((l >> 1) & 1) << 2) | (l & 0x38);
 }
 
 template <int KC>
@@ -152,11 +158,10 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
     // d(pixel)/d(ndc) = 0.5*W, 0.5*H (backward.cu:550-551); 1/log2(e) undoes the conic pre-scale
     const float kx = (0.5f * a.W) / HSR_LOG2E, ky = (0.5f * a.H) / HSR_LOG2E;
 
-    float acc0 = 0, acc1 = 0, acc2 = 0, accd = 0, acco = 0;
-    float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_depth = 0, last_op = 0;
+    float Rb = 0.f, last_h = 0.f, last_alpha = 0.f;  // blended "colour . gradient" behind the current splat
 
     // per-lane atomic target for the value this lane ends up holding after the transposing reduction
-    const int myv = bitrev6(lane);
+    const int myv = reduce_slot(lane);
     float* tgt_base = nullptr;
     int tgt_stride = 0;
     if (BASE) {
@@ -239,25 +244,20 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
                 float v[NV];
                 if (BASE) {
                     const float4 cd = s_col[j];
-                    float dL_dalpha = 0.f;
-                    // colour channels (backward.cu:604-617)
-                    const float a0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                    const float a1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                    const float a2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                    dL_dalpha += (cd.x - a0) * dpx0;
-                    dL_dalpha += (cd.y - a1) * dpx1;
-                    dL_dalpha += (cd.z - a2) * dpx2;
+                    // The reference keeps one "colour behind me" accumulator per channel (rgb, depth and the
+                    // opacity channel of ones: backward.cu:604-632) and dots each with its upstream gradient.
+                    // The recurrence is linear, so the dot product can be taken first: one scalar
+                    //   h = c . dL_dpixel,   R <- last_alpha * last_h + (1 - last_alpha) * R,
+                    // gives dL_dalpha = (h - R) * T_before, identical up to fp32 rounding with 3 state
+                    // registers instead of 11 and a third of the instructions.
+                    const float h = fmaf(cd.x, dpx0, fmaf(cd.y, dpx1, fmaf(cd.z, dpx2, fmaf(cd.w, dpd, dpo))));
+                    const float Rn = fmaf(last_alpha, last_h - Rb, Rb);
+                    float dL_dalpha = (h - Rn) * test_T;
                     v[6] = w * dpx0;
                     v[7] = w * dpx1;
                     v[8] = w * dpx2;
                     // depth (+ median-depth gradient at the T = 0.5 crossing, backward.cu:618-626)
-                    const float ad = last_alpha * last_depth + (1.f - last_alpha) * accd;
-                    dL_dalpha += (cd.w - ad) * dpd;
                     v[9] = w * dpd + ((active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f);
-                    // final opacity as a channel of ones (backward.cu:628-632)
-                    const float ao = last_alpha * last_op + (1.f - last_alpha) * acco;
-                    dL_dalpha += (1.f - ao) * dpo;
-                    dL_dalpha *= test_T;
                     dL_dalpha += (-T_final * inv_one_m_a) * bg_dot;
                     // rejected lanes contribute nothing (and exp2 of a positive power may be inf)
                     const float Gs = active ? G : 0.f;
@@ -272,8 +272,8 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
                     v[4] = hq * dyy;
                     v[5] = fmaf(w, dpo, gda);
                     if (active) {
-                        acc0 = a0; acc1 = a1; acc2 = a2; accd = ad; acco = ao;
-                        lc0 = cd.x; lc1 = cd.y; lc2 = cd.z; last_depth = cd.w; last_op = 1.f;
+                        Rb = Rn;
+                        last_h = h;
                         last_alpha = alpha;
                     }
 #pragma unroll
