@@ -137,6 +137,7 @@ struct RenderBwdArgs {
     float* dL_ddepth;     // [P]
 };
 int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream);
+int hsr_launch_render_backward_mfma(const RenderBwdArgs& a, hipStream_t stream);
 
 struct PreBwdArgs {
     int P, D, M;

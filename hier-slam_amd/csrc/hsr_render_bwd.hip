@@ -16,89 +16,13 @@
 // per lane.  One global_atomic_add_f32 wave-instruction
 // per (wave, splat) then carries all 10+K sums.  Waves own 8x8 quadrants and walk compacted
 // per-quadrant lists (hsr_tile_common.h); of the survivors, a splat no lane accepts is skipped.
+#include <stdlib.h>
+#include <string.h>
+
 #include "hsr_tile_common.h"
+#include "hsr_wave_reduce.h"
 
 namespace {
-
-// ---- cross-lane helpers (gfx950) ----
-typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-
-// lanes 0-31 <- x.lo + x.hi ; lanes 32-63 <- y.lo + y.hi
-__device__ __forceinline__ float pair32(float x, float y)
-{
-    const uint2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// rows (16 lanes) with bit4 = 0 <- x.row(2i) + x.row(2i+1) ; bit4 = 1 <- y.row(2i) + y.row(2i+1)
-__device__ __forceinline__ float pair16(float x, float y)
-{
-    const uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));
-}
-// lanes with `bit` clear keep x (+ partner's x), lanes with it set keep y (+ partner's y)
-template <int CTRL>
-__device__ __forceinline__ float pair_dpp(float x, float y, bool bit)
-{
-    const float keep = bit ? y : x;
-    const float send = bit ? x : y;
-    return keep + dpp_mov<CTRL>(send);
-}
-
-constexpr int DPP_ROW_ROR8 = 0x128;
-constexpr int DPP_ROW_HALF_MIRROR = 0x141;
-constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm [2,3,0,1]
-constexpr int DPP_QUAD_XOR1 = 0xB1;  // quad_perm [1,0,3,2]
-
-// Sums each of the N per-lane values over the 64 lanes of the wave; lane l returns the total of
-// v[reduce_slot(l)] (don't-care where that index is >= N).  Stage order is chosen by instruction cost on gfx950: the four
-// in-row stages (quad_perm xor 1, xor 2, row_half_mirror, row_ror:8) are full-rate DPP adds and run
-// while there are many registers; the two cross-row stages (v_permlane16_swap, v_permlane32_swap —
-// slower, with hazard wait states) run last on the 3 and 2 registers that are left.
-template <int M>
-__device__ __forceinline__ float elem_or_zero(const float (&x)[M], int i)
-{
-    return i < M ? x[i < M ? i : 0] : 0.f;
-}
-
-template <int N>
-__device__ __forceinline__ float wave_reduce_transpose(const float (&v)[N], int lane)
-{
-    static_assert(N >= 1 && N <= 64, "at most one value per lane");
-    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
-    static_assert((N5 + 1) / 2 == 1, "six stages reduce to one register");
-    float a[N1], b[N2], c[N3], d[N4], e[N5];
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-#pragma unroll
-    // row_half_mirror pairs l with 7-l (flips bits 0..2), so it must come first: each later pairing
-    // (xor 1, xor 2, xor 8, xor 16, xor 32) then joins lanes that agree on every earlier select bit
-    for (int i = 0; i < N1; i++) a[i] = pair_dpp<DPP_ROW_HALF_MIRROR>(v[2 * i], elem_or_zero(v, 2 * i + 1), b2);
-#pragma unroll
-    for (int i = 0; i < N2; i++) b[i] = pair_dpp<DPP_QUAD_XOR1>(a[2 * i], elem_or_zero(a, 2 * i + 1), b0);
-#pragma unroll
-    for (int i = 0; i < N3; i++) c[i] = pair_dpp<DPP_QUAD_XOR2>(b[2 * i], elem_or_zero(b, 2 * i + 1), b1);
-#pragma unroll
-    for (int i = 0; i < N4; i++) d[i] = pair_dpp<DPP_ROW_ROR8>(c[2 * i], elem_or_zero(c, 2 * i + 1), b3);
-#pragma unroll
-    for (int i = 0; i < N5; i++) e[i] = pair16(d[2 * i], elem_or_zero(d, 2 * i + 1));
-    return pair32(e[0], elem_or_zero(e, 1));
-}
-
-// which value a lane holds after wave_reduce_transpose: select bits in stage order b2, b0, b1, b3, b4, b5
-__device__ __forceinline__ int reduce_slot(int l)
-{
-    return ((l >> 2) & 1) | ((l & 1) << 1) | (((l >> 1) & 1) << 2) | (l & 0x38);
-}
-
-template <int KC>
-struct BwdCfg {
-    static constexpr int NV = 10 + KC;  // mean2D.xy, conic.xyw, opacity, rgb, depth, sem[KC]
-    static constexpr int NV_SEMONLY = KC;
-};
 
 // BASE: this launch produces the 10 geometric/colour sums (and the first KC semantic channels);
 // !BASE: semantic channels [c0, c0+KC) only (generic-K chunking).
@@ -113,6 +37,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
     __shared__ int s_id[BATCH];
     __shared__ uint8_t s_list[4][256];
     __shared__ uint8_t s_lcnt[4][4];
+    __shared__ uint8_t s_flat[4][256];
     __shared__ int s_wmax[4];
 
     const int tile = blockIdx.x;
@@ -221,13 +146,26 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
         load_id(hi - 2 * BATCH);
         if (hi - cnt >= wmax) continue;  // this wave's pixels all stopped in front of this batch
 
-        for (int seg = 0; seg < 4; seg++) {
-            const int m = s_lcnt[wv][seg];
-            for (int k = 0; k < m; k++) {
-                const int j = s_list[wv][seg * 64 + k];
+        const int total = build_flat_list(wv, lane, s_list, s_lcnt, s_flat);
+        {
+            // slot + record of the next splat are fetched one iteration ahead (stale tail entries are
+            // fetched and never used)
+            int j1 = s_flat[wv][0];
+            float4 gn = s_geo[j1];
+            float2 con = s_co[j1];
+            float4 cdn = s_col[j1];
+            int j2 = s_flat[wv][1];
+            for (int i = 0; i < total; i++) {
+                const int j = j1;
+                const float4 g = gn;
+                const float2 co = con;
+                const float4 cd = cdn;
+                j1 = j2;
+                gn = s_geo[j1];
+                con = s_co[j1];
+                cdn = s_col[j1];
+                j2 = s_flat[wv][(i + 2) & 255];
                 const int pos = hi - 1 - j;  // 0-based list position == reference `contributor` after decrement
-                const float4 g = s_geo[j];
-                const float2 co = s_co[j];
                 const float dx = g.x - pfx, dy = g.y - pfy;
                 const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
                 const float power2 = fmaf(co.x, dyy, fmaf(g.w, dxy, g.z * dxx));  // log2(G)
@@ -243,7 +181,6 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
                 const float w = active ? alpha * test_T : 0.f;
                 float v[NV];
                 if (BASE) {
-                    const float4 cd = s_col[j];
                     // The reference keeps one "colour behind me" accumulator per channel (rgb, depth and the
                     // opacity channel of ones: backward.cu:604-632) and dots each with its upstream gradient.
                     // The recurrence is linear, so the dot product can be taken first: one scalar
@@ -301,6 +238,15 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
     const dim3 grid(tiles), block(256);
+    // default: matrix-core path (hsr_render_bwd_mfma.hip) for the base sums + the first 27 semantic channels,
+    // VALU chunks for the rest.  HSR_BWD_IMPL=valu selects the all-VALU kernels below (A/B timing, debugging).
+    static const bool use_valu = getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "valu");
+    if (!use_valu) {
+        hsr_launch_render_backward_mfma(a, stream);
+        const int K = a.semantic ? a.K : 0;
+        for (int c0 = 27; c0 < K; c0 += 32) render_bwd_kernel<32, false><<<grid, block, 0, stream>>>(a, c0);
+        return HSR_OK;
+    }
     if (!a.semantic || a.K == 0) {
         render_bwd_kernel<0, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;

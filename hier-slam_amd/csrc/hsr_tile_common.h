@@ -88,3 +88,21 @@ __device__ __forceinline__ void publish_quadrant_lists(uint32_t qmask, int t, ui
         if (lane == 0) s_lcnt[q][sw] = (uint8_t)__popcll(m);
     }
 }
+
+// Consumer side: the wave that owns quadrant `wv` concatenates its four segments into one flat list
+// (wave-local LDS traffic, no barrier: LDS operations of one wave execute in order).  A flat list lets
+// the blend loop prefetch the next splat's slot and record one iteration ahead, which matters because
+// with 3-5 waves per SIMD an exposed LDS round trip per splat is not hidden by other waves.
+__device__ __forceinline__ int build_flat_list(int wv, int lane, const uint8_t (*s_list)[256], const uint8_t (*s_lcnt)[4],
+                                               uint8_t (*s_flat)[256])
+{
+    int total = 0;
+#pragma unroll
+    for (int seg = 0; seg < 4; seg++) {
+        const int c = s_lcnt[wv][seg];
+        if (lane < c) s_flat[wv][total + lane] = s_list[wv][seg * 64 + lane];
+        total += c;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return total;
+}
