@@ -277,6 +277,8 @@ struct BwdIn {
     const float *dL_dpix, *dL_dpix_sem, *dL_dpix_depth, *dL_dpix_median, *dL_dpix_opacity;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dsemantics, *dL_ddepth, *dL_dmean3D, *dL_dcov3D, *dL_dsh,
         *dL_dscale, *dL_drot;
+    char* scratch;
+    size_t scratch_bytes;
 };
 
 // the sums the tile kernel accumulates atomically start from zero (the reference relies on the
@@ -336,7 +338,23 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     const int* radii = in.radii ? in.radii : g.radii;
     const int K = in.semantic ? in.K : 0;
 
-    if ((rc = zero_accumulators(in, K, stream)) != HSR_OK) return rc;
+    // deterministic path: per-instance rows + per-Gaussian sum (no atomics, no zero-fill) whenever the caller
+    // passes scratch and K is covered; otherwise the fp32-atomic kernels (HSR_BWD_IMPL=valu|mfma picks which)
+    const bool use_rows = in.scratch && hsr_rows_supported(K) && in.R > 0 &&
+                          in.scratch_bytes >= hsr_backward_scratch_bytes(P, K, in.R);
+    int rows_kc = 0;
+    float* rows = nullptr;
+    uint32_t* inv = nullptr;
+    if (use_rows) {
+        char* sp = in.scratch;
+        take(sp, rows, (size_t)in.R * (size_t)hsr_rows_row_floats(K));
+        take(sp, inv, (size_t)in.R);
+        // SH coefficients above the active degree (and those of culled Gaussians) receive no gradient
+        if (!in.colors_precomp && in.shs && in.dL_dsh && in.M > 0)
+            HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsh, 0, sizeof(float) * 3 * (size_t)in.M * (size_t)P, stream));
+    } else {
+        if ((rc = zero_accumulators(in, K, stream)) != HSR_OK) return rc;
+    }
 
     if (in.R > 0) {
         RenderBwdArgs ra;
@@ -352,12 +370,17 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         ra.dL_dpix_median = in.dL_dpix_median; ra.dL_dpix_opacity = in.dL_dpix_opacity;
         ra.dL_dmean2D = in.dL_dmean2D; ra.dL_dconic = in.dL_dconic; ra.dL_dopacity = in.dL_dopacity;
         ra.dL_dcolor = in.dL_dcolor; ra.dL_dsemantics = in.dL_dsemantics; ra.dL_ddepth = in.dL_ddepth;
-        {
-            StageTimer tm(HSR_STAGE_BWD_RENDER, stream);
+        ra.rows = rows;
+        StageTimer tm(HSR_STAGE_BWD_RENDER, stream);
+        if (use_rows) {
+            const int tiles_x = (W + HSR_TILE_X - 1) / HSR_TILE_X, tiles_y = (H + HSR_TILE_Y - 1) / HSR_TILE_Y;
+            hsr_launch_inverse_map(in.R, tiles_x, tiles_y, b.keys, b.vals, g.means2D, radii, g.point_offsets, inv, stream);
+            rows_kc = hsr_launch_render_backward_rows(ra, stream);
+        } else {
             hsr_launch_render_backward(ra, stream);
         }
-        HSR_LAUNCH_CHECK(in.debug, stream);
     }
+    HSR_LAUNCH_CHECK(in.debug, stream);
 
     PreBwdArgs pb;
     pb.P = P; pb.D = in.D; pb.M = in.M; pb.means3D = in.means3D; pb.radii = radii;
@@ -369,6 +392,9 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     pb.dL_dmean2D = in.dL_dmean2D; pb.dL_dconic = in.dL_dconic; pb.dL_dmean3D = in.dL_dmean3D; pb.dL_dcolor = in.dL_dcolor;
     pb.dL_ddepth = in.dL_ddepth; pb.dL_dcov3D = in.dL_dcov3D; pb.dL_dsh = in.dL_dsh; pb.dL_dscale = in.dL_dscale;
     pb.dL_drot = in.dL_drot;
+    pb.rows_kc = rows_kc; pb.K = K; pb.rows = rows; pb.inv = inv; pb.point_offsets = g.point_offsets;
+    pb.out_mean2D = in.dL_dmean2D; pb.out_conic = in.dL_dconic; pb.out_opacity = in.dL_dopacity; pb.out_color = in.dL_dcolor;
+    pb.out_semantics = in.dL_dsemantics; pb.out_depth = in.dL_ddepth;
     if (pb.shs && (!in.dL_dsh || !in.campos)) {
         hsr_set_error("shs given without dL_dsh / campos");
         return HSR_ERR_INVALID_ARGUMENT;
@@ -441,6 +467,12 @@ extern "C" {
 size_t hsr_required_geometry_bytes(int P) { return hsr_carve_geom(nullptr, P, nullptr) + 256; }
 size_t hsr_required_image_bytes(int width, int height) { return hsr_carve_img(nullptr, width, height, nullptr) + 256; }
 size_t hsr_required_binning_bytes(int num_rendered) { return hsr_carve_bin(nullptr, num_rendered, nullptr) + 256; }
+size_t hsr_backward_scratch_bytes(int P, int K, int num_rendered)
+{
+    (void)P;
+    if (!hsr_rows_supported(K) || num_rendered <= 0) return 0;
+    return (size_t)num_rendered * ((size_t)hsr_rows_row_floats(K) * 4 + 4) + 1024;
+}
 
 const char* hsr_last_error(void) { return g_err; }
 
@@ -553,9 +585,10 @@ int hsr_backward(int P, int D, int M, int R, const float* background, int width,
                  const char* binning_buffer, const char* img_buffer, const float* dL_dpix, const float* dL_dpix_depth,
                  const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity, float* dL_dmean2D, float* dL_dconic,
                  float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                 float* dL_dscale, float* dL_drot, int debug, void* stream)
+                 float* dL_dscale, float* dL_drot, char* scratch, size_t scratch_bytes, int debug, void* stream)
 {
     BwdIn in;
+    in.scratch = scratch; in.scratch_bytes = scratch_bytes;
     in.P = P; in.D = D; in.M = M; in.K = 0; in.semantic = 0; in.R = R; in.W = width; in.H = height; in.debug = debug;
     in.background = background; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.semantics = nullptr;
     in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.viewmatrix = viewmatrix;
@@ -577,10 +610,11 @@ int hsr_backward_semantic(int P, int D, int M, int K, int R, const float* backgr
                           const float* dL_dpix, const float* dL_dpix_semantic, const float* dL_dpix_depth,
                           const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity, float* dL_dmean2D,
                           float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantics, float* dL_ddepth,
-                          float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                          void* stream)
+                          float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                          char* scratch, size_t scratch_bytes, int debug, void* stream)
 {
     BwdIn in;
+    in.scratch = scratch; in.scratch_bytes = scratch_bytes;
     in.P = P; in.D = D; in.M = M; in.K = K; in.semantic = 1; in.R = R; in.W = width; in.H = height; in.debug = debug;
     in.background = background; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.semantics = semantics_precomp;
     in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.viewmatrix = viewmatrix;

@@ -107,10 +107,47 @@ __device__ void sh_backward(int idx, int deg, int max_coeffs, float mx, float my
     gmz += (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
 }
 
+// KC < 0: legacy mode (sums already accumulated atomically in dL_dmean2D / dL_dconic / dL_ddepth).
+// KC >= 0: rows mode — this thread first sums the rows of its Gaussian's instances (emission order = ascending
+// tile id inside its rect, a FIXED order: gradients are bit-reproducible), writes the six per-Gaussian sums
+// the tile kernel used to add atomically, and continues with them in registers.
+template <int KC>
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.P) return;
+    float g_m2x = 0, g_m2y = 0, g_cx = 0, g_cy = 0, g_cw = 0, g_depth = 0;
+    if (KC >= 0) {
+        constexpr int NCHP = 16 * ((KC + 5 + 15) / 16);
+        constexpr int ROW = 8 + NCHP;
+        float racc[ROW];
+#pragma unroll
+        for (int c = 0; c < ROW; c++) racc[c] = 0.f;
+        const uint32_t beg = idx == 0 ? 0u : a.point_offsets[idx - 1], end = a.point_offsets[idx];
+        for (uint32_t u = beg; u < end; u++) {
+            const float4* r = reinterpret_cast<const float4*>(a.rows + (size_t)a.inv[u] * ROW);
+#pragma unroll
+            for (int q = 0; q < ROW / 4; q++) {
+                const float4 v = r[q];
+                racc[4 * q] += v.x; racc[4 * q + 1] += v.y; racc[4 * q + 2] += v.z; racc[4 * q + 3] += v.w;
+            }
+        }
+        constexpr int KCC = KC < 0 ? 0 : KC;
+        g_m2x = racc[0]; g_m2y = racc[1]; g_cx = racc[2]; g_cy = racc[3]; g_cw = racc[4];
+        g_depth = racc[6] + racc[8 + KCC + 3];
+        a.out_mean2D[3 * idx] = g_m2x; a.out_mean2D[3 * idx + 1] = g_m2y; a.out_mean2D[3 * idx + 2] = 0.f;
+        reinterpret_cast<float4*>(a.out_conic)[idx] = make_float4(g_cx, g_cy, 0.f, g_cw);
+        a.out_opacity[idx] = racc[5] + racc[8 + KCC + 4];
+        a.out_color[3 * idx] = racc[8 + KCC]; a.out_color[3 * idx + 1] = racc[8 + KCC + 1]; a.out_color[3 * idx + 2] = racc[8 + KCC + 2];
+        a.out_depth[idx] = g_depth;
+#pragma unroll
+        for (int c = 0; c < KCC; c++)
+            if (c < a.K) a.out_semantics[(size_t)idx * a.K + c] = racc[8 + c];
+    } else {
+        g_m2x = a.dL_dmean2D[3 * idx]; g_m2y = a.dL_dmean2D[3 * idx + 1];
+        g_cx = a.dL_dconic[4 * idx]; g_cy = a.dL_dconic[4 * idx + 1]; g_cw = a.dL_dconic[4 * idx + 3];
+        g_depth = a.dL_ddepth[idx];
+    }
     float gmx = 0, gmy = 0, gmz = 0;
     float dcov[6] = {0, 0, 0, 0, 0, 0};
     float dsc[3] = {0, 0, 0};
@@ -123,7 +160,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
         // ---- conic -> cov2D -> cov3D, mean (backward.cu:144-274) ----
         {
             const float* cov3D = a.cov3Ds + 6 * (size_t)idx;
-            const float dcx = a.dL_dconic[4 * idx], dcy = a.dL_dconic[4 * idx + 1], dcz = a.dL_dconic[4 * idx + 3];
+            const float dcx = g_cx, dcy = g_cy, dcz = g_cw;
             float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
             float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
             const float tz_ = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
@@ -189,12 +226,12 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
             const float m_w = 1.0f / (hw + 0.0000001f);
             const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
             const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
-            const float d2x = a.dL_dmean2D[3 * idx], d2y = a.dL_dmean2D[3 * idx + 1];
+            const float d2x = g_m2x, d2y = g_m2y;
             gmx += (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
             gmy += (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
             gmz += (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
             const float mul3 = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
-            const float dd = a.dL_ddepth[idx];
+            const float dd = g_depth;
             gmx += (vm[2] - vm[3] * mul3) * dd;
             gmy += (vm[6] - vm[7] * mul3) * dd;
             gmz += (vm[10] - vm[11] * mul3) * dd;
@@ -257,6 +294,14 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
 int hsr_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t stream)
 {
     if (a.P <= 0) return HSR_OK;
-    preprocess_backward_kernel<<<(a.P + 255) / 256, 256, 0, stream>>>(a);
+    const dim3 grid((a.P + 255) / 256), block(256);
+    switch (a.rows_kc) {
+    case 0: preprocess_backward_kernel<-1><<<grid, block, 0, stream>>>(a); break;
+    case 11: preprocess_backward_kernel<11><<<grid, block, 0, stream>>>(a); break;
+    case 16: preprocess_backward_kernel<16><<<grid, block, 0, stream>>>(a); break;
+    case 26: preprocess_backward_kernel<26><<<grid, block, 0, stream>>>(a); break;
+    case 27: preprocess_backward_kernel<27><<<grid, block, 0, stream>>>(a); break;
+    default: hsr_set_error("unsupported rows_kc %d", a.rows_kc); return HSR_ERR_INVALID_ARGUMENT;
+    }
     return HSR_OK;
 }

@@ -135,9 +135,15 @@ struct RenderBwdArgs {
     float* dL_dcolor;     // [P,3]
     float* dL_dsemantics; // [P,K]
     float* dL_ddepth;     // [P]
+    float* rows;          // rows mode: [R][ROW] per-instance sums (scratch)
 };
 int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream);
 int hsr_launch_render_backward_mfma(const RenderBwdArgs& a, hipStream_t stream);
+int hsr_launch_render_backward_rows(const RenderBwdArgs& a, hipStream_t stream);  // returns the kernel's KC
+int hsr_rows_row_floats(int K);
+bool hsr_rows_supported(int K);
+int hsr_launch_inverse_map(int R, int tiles_x, int tiles_y, const uint64_t* keys, const uint32_t* vals, const float2* means2D,
+                           const int* radii, const uint32_t* offsets, uint32_t* inv, hipStream_t stream);
 
 struct PreBwdArgs {
     int P, D, M;
@@ -162,6 +168,14 @@ struct PreBwdArgs {
     float* dL_dsh;
     float* dL_dscale;
     float* dL_drot;
+    // rows mode (deterministic backward): per-instance rows are summed per Gaussian here, and the sums are
+    // written to the out_* arrays (then used in place of the dL_dmean2D / dL_dconic / dL_ddepth inputs)
+    int rows_kc;             // 0 = legacy (atomic) mode; else the KC the rows kernel was instantiated for
+    int K;
+    const float* rows;       // [R][8 + 16*NG]
+    const uint32_t* inv;     // emission index -> sorted position
+    const uint32_t* point_offsets;
+    float *out_mean2D, *out_conic, *out_opacity, *out_color, *out_semantics, *out_depth;
 };
 int hsr_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t stream);
 

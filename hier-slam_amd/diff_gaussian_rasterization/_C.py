@@ -64,10 +64,13 @@ def _load():
                                          cf, cf, ci, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.hsr_backward.restype = ci
     lib.hsr_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp,
-                                 vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+                                 vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
+    lib.hsr_backward_scratch_bytes.restype = sz
+    lib.hsr_backward_scratch_bytes.argtypes = [ci, ci, ci]
     lib.hsr_backward_semantic.restype = ci
     lib.hsr_backward_semantic.argtypes = [ci, ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf,
-                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz,
+                                          ci, vp]
     lib.hsr_stage_name.restype = C.c_char_p
     lib.hsr_stage_name.argtypes = [ci]
     lib.hsr_profile_enable.restype = ci
@@ -85,6 +88,9 @@ _lib = _load()
 # state needs no grow callback (the reference resizes through a callback every call,
 # rasterize_points.cu:27-33)
 _binning_hint = {}
+
+# set True (or HSR_BWD_IMPL=rows) for the experimental backward without global atomics
+deterministic_backward = os.environ.get("HSR_BWD_IMPL", "") == "rows"
 
 
 def version():
@@ -248,8 +254,13 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
                                             dL_dout_final_opacity)]
             bg_, m3_, sh_, col_, sem_, sc_, rot_, cov_, vm_, pm_, cp_, gcol, gsem, gdep, gmed, gop = tens
             radii_ = _prep(radii, dev, torch.int32)
+            # Experimental backward without global atomics (per-instance rows + per-Gaussian sum): opt-in, currently
+            # ~5 % slower end to end than the fp32-atomic kernels.  It needs a scratch buffer of
+            # per-instance gradient rows; 0 bytes = not covered for this K.
+            nscratch = int(_lib.hsr_backward_scratch_bytes(P, K, int(R))) if deterministic_backward else 0
+            scratch = torch.empty(nscratch, dtype=torch.uint8, device=dev) if nscratch else None
             common_tail = (_ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
-                           int(bool(debug)), stream)
+                           _ptr(scratch), nscratch, int(bool(debug)), stream)
             if semantic:
                 rc = _lib.hsr_backward_semantic(
                     P, int(degree), M, K, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sem_), _ptr(sc_),

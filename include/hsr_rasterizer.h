@@ -60,6 +60,10 @@ typedef struct hsr_buffer {
 size_t hsr_required_geometry_bytes(int P);
 size_t hsr_required_image_bytes(int width, int height);
 size_t hsr_required_binning_bytes(int num_rendered);
+/* Size of the optional backward scratch (per-instance gradient rows + inverse permutation) that enables the
+ * experimental backward without global atomics; 0 when that path does not cover K (K > 27).  The reference allocates its
+ * backward scratch itself with cudaMalloc/cudaFree per call (rasterizer_impl.cu:673-701); here the caller owns it. */
+size_t hsr_backward_scratch_bytes(int P, int K, int num_rendered);
 
 /* Thread-local text of the last error returned by any hsr_* call on this thread. */
 const char* hsr_last_error(void);
@@ -100,7 +104,10 @@ int hsr_forward_semantic(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* 
  * R = num_rendered returned by the matching hsr_forward; the three buffers are the ones it filled.
  * dL_dmean2D is [P,3] (z unused), dL_dconic [P,4] (.z unused), dL_dopacity [P], dL_dcolor [P,3],
  * dL_ddepth [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4].
- * All are fully overwritten. */
+ * All are fully overwritten.
+ * scratch: device buffer of hsr_backward_scratch_bytes(P, K, R) bytes, or NULL.  With it the backward uses no
+ * global atomics (per-instance rows, then a per-Gaussian sum); without it (or for K > 27) the sums are
+ * accumulated with fp32 global atomics like the reference.  Either way last bits are order-dependent. */
 int hsr_backward(int P, int D, int M, int R, const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -111,7 +118,7 @@ int hsr_backward(int P, int D, int M, int R, const float* background, int width,
                  const float* dL_dpix_final_opacity,
                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                 int debug, void* stream);
+                 char* scratch, size_t scratch_bytes, int debug, void* stream);
 
 /* Replaces Rasterizer::backward_semantic (rasterizer.h:130-162, rasterizer_impl.cu:614-731).
  * dL_dpix_semantic is [K,H,W], dL_dsemantics [P,K].  The semantic loss reaches only dL_dsemantics:
@@ -129,7 +136,7 @@ int hsr_backward_semantic(int P, int D, int M, int K, int R, const float* backgr
                           float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                           float* dL_dsemantics, float* dL_ddepth,
                           float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                          int debug, void* stream);
+                          char* scratch, size_t scratch_bytes, int debug, void* stream);
 
 /* Read-only view into the opaque state buffers, for parity tests and debugging only (the reference
  * keeps the same fields in GeometryState / BinningState / ImageState, rasterizer_impl.h:29-64).
