@@ -17,7 +17,7 @@
 #include <vector>
 
 #include "../../include/hsr_rasterizer.h"
-#include "hsr_common.h"
+#include "hsr_tile_common.h"
 
 namespace {
 
@@ -42,6 +42,19 @@ uint32_t higher_msb(uint32_t n)  // reference getHigherMsb, rasterizer_impl.cu:3
     if (n >> msb) msb++;
     return msb;
 }
+
+// backward accumulation mode: 0 packed per-Gaussian rows (default), 1 per-instance rows (experimental),
+// 2 legacy separate arrays.  Initialised from HSR_BWD_IMPL=rows|legacy, changed with hsr_set_backward_mode().
+int g_bwd_mode = -1;
+int backward_mode()
+{
+    if (g_bwd_mode < 0) {
+        const char* e = getenv("HSR_BWD_IMPL");
+        g_bwd_mode = (e && !strcmp(e, "rows")) ? 1 : (e && !strcmp(e, "legacy")) ? 2 : 0;
+    }
+    return g_bwd_mode;
+}
+bool rows_mode_requested() { return backward_mode() == 1; }
 
 int acquire(hsr_buffer* b, size_t need, const char* what, char** out)
 {
@@ -338,10 +351,18 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     const int* radii = in.radii ? in.radii : g.radii;
     const int K = in.semantic ? in.K : 0;
 
-    // deterministic path: per-instance rows + per-Gaussian sum (no atomics, no zero-fill) whenever the caller
-    // passes scratch and K is covered; otherwise the fp32-atomic kernels (HSR_BWD_IMPL=valu|mfma picks which)
-    const bool use_rows = in.scratch && hsr_rows_supported(K) && in.R > 0 &&
+    // Accumulation modes (hsr_backward_scratch_bytes() sizes the scratch for the one in force):
+    //   packed (default with scratch): fp32 atomics into ONE 64-byte-aligned row per Gaussian, unpacked by
+    //       the per-Gaussian kernel — half the atomic requests of the reference's six separate arrays;
+    //   rows (HSR_BWD_IMPL=rows, K <= 27): per-instance rows, no global atomics (experimental);
+    //   legacy (no scratch): atomics straight into the six output arrays.
+    const bool want_rows = rows_mode_requested();
+    const bool use_rows = want_rows && in.scratch && hsr_rows_supported(K) && in.R > 0 &&
                           in.scratch_bytes >= hsr_backward_scratch_bytes(P, K, in.R);
+    const int gstride = hsr_grow_stride(K);
+    const bool use_packed = !use_rows && backward_mode() != 2 && in.scratch &&
+                            in.scratch_bytes >= (size_t)P * gstride * sizeof(float) + 256;
+    float* grow = nullptr;
     int rows_kc = 0;
     float* rows = nullptr;
     uint32_t* inv = nullptr;
@@ -350,6 +371,13 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         take(sp, rows, (size_t)in.R * (size_t)hsr_rows_row_floats(K));
         take(sp, inv, (size_t)in.R);
         // SH coefficients above the active degree (and those of culled Gaussians) receive no gradient
+        if (!in.colors_precomp && in.shs && in.dL_dsh && in.M > 0)
+            HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsh, 0, sizeof(float) * 3 * (size_t)in.M * (size_t)P, stream));
+    } else if (use_packed) {
+        char* sp = in.scratch;
+        take(sp, grow, (size_t)P * gstride);
+        StageTimer tm(HSR_STAGE_BWD_ZERO, stream);
+        HSR_HIP_CHECK(hipMemsetAsync(grow, 0, sizeof(float) * (size_t)P * gstride, stream));
         if (!in.colors_precomp && in.shs && in.dL_dsh && in.M > 0)
             HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsh, 0, sizeof(float) * 3 * (size_t)in.M * (size_t)P, stream));
     } else {
@@ -371,6 +399,8 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         ra.dL_dmean2D = in.dL_dmean2D; ra.dL_dconic = in.dL_dconic; ra.dL_dopacity = in.dL_dopacity;
         ra.dL_dcolor = in.dL_dcolor; ra.dL_dsemantics = in.dL_dsemantics; ra.dL_ddepth = in.dL_ddepth;
         ra.rows = rows;
+        ra.grow = grow;
+        ra.grow_stride = gstride;
         StageTimer tm(HSR_STAGE_BWD_RENDER, stream);
         if (use_rows) {
             const int tiles_x = (W + HSR_TILE_X - 1) / HSR_TILE_X, tiles_y = (H + HSR_TILE_Y - 1) / HSR_TILE_Y;
@@ -395,6 +425,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     pb.rows_kc = rows_kc; pb.K = K; pb.rows = rows; pb.inv = inv; pb.point_offsets = g.point_offsets;
     pb.out_mean2D = in.dL_dmean2D; pb.out_conic = in.dL_dconic; pb.out_opacity = in.dL_dopacity; pb.out_color = in.dL_dcolor;
     pb.out_semantics = in.dL_dsemantics; pb.out_depth = in.dL_ddepth;
+    pb.grow = grow; pb.grow_stride = gstride;
     if (pb.shs && (!in.dL_dsh || !in.campos)) {
         hsr_set_error("shs given without dL_dsh / campos");
         return HSR_ERR_INVALID_ARGUMENT;
@@ -469,12 +500,23 @@ size_t hsr_required_image_bytes(int width, int height) { return hsr_carve_img(nu
 size_t hsr_required_binning_bytes(int num_rendered) { return hsr_carve_bin(nullptr, num_rendered, nullptr) + 256; }
 size_t hsr_backward_scratch_bytes(int P, int K, int num_rendered)
 {
-    (void)P;
-    if (!hsr_rows_supported(K) || num_rendered <= 0) return 0;
-    return (size_t)num_rendered * ((size_t)hsr_rows_row_floats(K) * 4 + 4) + 1024;
+    if (P <= 0 || K < 0 || backward_mode() == 2) return 0;
+    if (rows_mode_requested() && hsr_rows_supported(K) && num_rendered > 0)
+        return (size_t)num_rendered * ((size_t)hsr_rows_row_floats(K) * 4 + 4) + 1024;
+    return (size_t)P * hsr_grow_stride(K) * sizeof(float) + 512;  // packed per-Gaussian rows
 }
 
 const char* hsr_last_error(void) { return g_err; }
+
+int hsr_set_backward_mode(int mode)
+{
+    if (mode < 0 || mode > 2) {
+        hsr_set_error("backward mode must be 0 (packed), 1 (rows) or 2 (legacy)");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    g_bwd_mode = mode;
+    return HSR_OK;
+}
 
 int hsr_profile_enable(int on)
 {

@@ -7,7 +7,7 @@
 // the three dL_dmean3D contributions in registers (one write instead of a write + two
 // read-modify-writes) and writes zeros for culled Gaussians, so callers need no zero-fill.
 // Memory-bound streaming: ~130 B read + ~90 B written per visible Gaussian.
-#include "hsr_common.h"
+#include "hsr_tile_common.h"
 
 namespace {
 
@@ -115,6 +115,16 @@ template <int KC>
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (KC < 0 && a.grow && a.K > 0) {
+        // packed mode: the block unpacks the semantic columns of its 256 rows cooperatively — consecutive
+        // lanes read consecutive floats of a row and write one contiguous [256, K] slab of dL_dsemantics
+        const int g0 = blockIdx.x * 256;
+        const int ng = min(256, a.P - g0);
+        for (int e = threadIdx.x; e < ng * a.K; e += 256) {
+            const int gi = e / a.K, c = e - gi * a.K;
+            a.out_semantics[(size_t)g0 * a.K + e] = a.grow[(size_t)(g0 + gi) * a.grow_stride + HSR_GROW_SEM0 + c];
+        }
+    }
     if (idx >= a.P) return;
     float g_m2x = 0, g_m2y = 0, g_cx = 0, g_cy = 0, g_cw = 0, g_depth = 0;
     if (KC >= 0) {
@@ -143,6 +153,17 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
 #pragma unroll
         for (int c = 0; c < KCC; c++)
             if (c < a.K) a.out_semantics[(size_t)idx * a.K + c] = racc[8 + c];
+    } else if (a.grow) {
+        // packed mode: unpack this Gaussian's atomically accumulated row into the reference's arrays
+        const float4* r = reinterpret_cast<const float4*>(a.grow + (size_t)idx * a.grow_stride);
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        g_m2x = r0.x; g_m2y = r0.y; g_cx = r0.z; g_cy = r0.w; g_cw = r1.x;
+        g_depth = r1.z + r2.w;
+        a.out_mean2D[3 * idx] = g_m2x; a.out_mean2D[3 * idx + 1] = g_m2y; a.out_mean2D[3 * idx + 2] = 0.f;
+        reinterpret_cast<float4*>(a.out_conic)[idx] = make_float4(g_cx, g_cy, 0.f, g_cw);
+        a.out_opacity[idx] = r1.y + r3.x;
+        a.out_color[3 * idx] = r2.x; a.out_color[3 * idx + 1] = r2.y; a.out_color[3 * idx + 2] = r2.z;
+        a.out_depth[idx] = g_depth;
     } else {
         g_m2x = a.dL_dmean2D[3 * idx]; g_m2y = a.dL_dmean2D[3 * idx + 1];
         g_cx = a.dL_dconic[4 * idx]; g_cy = a.dL_dconic[4 * idx + 1]; g_cw = a.dL_dconic[4 * idx + 3];

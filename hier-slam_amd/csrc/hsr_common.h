@@ -136,6 +136,8 @@ struct RenderBwdArgs {
     float* dL_dsemantics; // [P,K]
     float* dL_ddepth;     // [P]
     float* rows;          // rows mode: [R][ROW] per-instance sums (scratch)
+    float* grow;          // packed mode: [P][grow_stride] one gradient row per Gaussian (scratch), else NULL
+    int grow_stride;
 };
 int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream);
 int hsr_launch_render_backward_mfma(const RenderBwdArgs& a, hipStream_t stream);
@@ -176,6 +178,9 @@ struct PreBwdArgs {
     const uint32_t* inv;     // emission index -> sorted position
     const uint32_t* point_offsets;
     float *out_mean2D, *out_conic, *out_opacity, *out_color, *out_semantics, *out_depth;
+    // packed mode: one atomically accumulated row per Gaussian (see hsr_grow_* in hsr_tile_common.h)
+    const float* grow;
+    int grow_stride;
 };
 int hsr_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t stream);
 

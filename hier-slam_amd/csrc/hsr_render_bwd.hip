@@ -89,7 +89,18 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
     const int myv = reduce_slot(lane);
     float* tgt_base = nullptr;
     int tgt_stride = 0;
-    if (BASE) {
+    if (a.grow) {
+        // packed per-Gaussian row (hsr_tile_common.h): one update = 144 contiguous bytes = 3 lines instead of 6
+        tgt_stride = a.grow_stride;
+        if (BASE) {
+            if (myv < 6) tgt_base = a.grow + myv;                                   // mean2D.xy, conic.xyw, opacity (total)
+            else if (myv < 9) tgt_base = a.grow + 8 + (myv - 6);                    // rgb
+            else if (myv == 9) tgt_base = a.grow + 6;                               // depth (total)
+            else if (myv < NV && c0 + (myv - 10) < a.K) tgt_base = a.grow + HSR_GROW_SEM0 + c0 + (myv - 10);
+        } else if (myv < NV && c0 + myv < a.K) {
+            tgt_base = a.grow + HSR_GROW_SEM0 + c0 + myv;
+        }
+    } else if (BASE) {
         if (myv < 2) { tgt_base = a.dL_dmean2D + myv; tgt_stride = 3; }
         else if (myv < 5) { tgt_base = a.dL_dconic + (myv == 4 ? 3 : myv - 2); tgt_stride = 4; }
         else if (myv == 5) { tgt_base = a.dL_dopacity; tgt_stride = 1; }

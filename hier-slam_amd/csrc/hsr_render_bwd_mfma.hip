@@ -110,7 +110,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
     const int myv = reduce_slot(lane);
     float* tgt_base = nullptr;
     int tgt_stride = 0;
-    if (myv < 2) { tgt_base = a.dL_dmean2D + myv; tgt_stride = 3; }
+    if (a.grow) {  // packed per-Gaussian row: the 7 butterfly values are columns 0..6 of one 64-byte line
+        if (myv < 7) { tgt_base = a.grow + myv; tgt_stride = a.grow_stride; }
+    } else if (myv < 2) { tgt_base = a.dL_dmean2D + myv; tgt_stride = 3; }
     else if (myv < 5) { tgt_base = a.dL_dconic + (myv == 4 ? 3 : myv - 2); tgt_stride = 4; }
     else if (myv == 5) { tgt_base = a.dL_dopacity; tgt_stride = 1; }
     else if (myv == 6) { tgt_base = a.dL_ddepth; tgt_stride = 1; }
@@ -140,7 +142,11 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
             const int ch = 16 * g + (lane & 15);
             mf_base[g] = nullptr;
             mf_stride[g] = 0;
-            if (ch < KC) { if (ch < a.K) { mf_base[g] = a.dL_dsemantics + ch; mf_stride[g] = a.K; } }
+            if (a.grow) {  // packed row: semantics from column 16, rgb / depth / opacity (direct parts) at 8..12
+                mf_stride[g] = a.grow_stride;
+                if (ch < KC) { if (ch < a.K) mf_base[g] = a.grow + HSR_GROW_SEM0 + ch; }
+                else if (ch < KC + 5) mf_base[g] = a.grow + 8 + (ch - KC);
+            } else if (ch < KC) { if (ch < a.K) { mf_base[g] = a.dL_dsemantics + ch; mf_stride[g] = a.K; } }
             else if (ch < KC + 3) { mf_base[g] = a.dL_dcolor + (ch - KC); mf_stride[g] = 3; }
             else if (ch == KC + 3) { mf_base[g] = a.dL_ddepth; mf_stride[g] = 1; }
             else if (ch == KC + 4) { mf_base[g] = a.dL_dopacity; mf_stride[g] = 1; }

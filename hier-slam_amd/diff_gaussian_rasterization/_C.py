@@ -65,6 +65,8 @@ def _load():
     lib.hsr_backward.restype = ci
     lib.hsr_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
+    lib.hsr_set_backward_mode.restype = ci
+    lib.hsr_set_backward_mode.argtypes = [ci]
     lib.hsr_backward_scratch_bytes.restype = sz
     lib.hsr_backward_scratch_bytes.argtypes = [ci, ci, ci]
     lib.hsr_backward_semantic.restype = ci
@@ -89,8 +91,11 @@ _lib = _load()
 # rasterize_points.cu:27-33)
 _binning_hint = {}
 
-# set True (or HSR_BWD_IMPL=rows) for the experimental backward without global atomics
-deterministic_backward = os.environ.get("HSR_BWD_IMPL", "") == "rows"
+def set_backward_mode(mode):
+    """'packed' (default), 'rows' (experimental, no global atomics) or 'legacy' (reference-style arrays)."""
+    rc = _lib.hsr_set_backward_mode({"packed": 0, "rows": 1, "legacy": 2}[mode])
+    if rc < 0:
+        _fail(rc, "hsr_set_backward_mode")
 
 
 def version():
@@ -254,10 +259,9 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
                                             dL_dout_final_opacity)]
             bg_, m3_, sh_, col_, sem_, sc_, rot_, cov_, vm_, pm_, cp_, gcol, gsem, gdep, gmed, gop = tens
             radii_ = _prep(radii, dev, torch.int32)
-            # Experimental backward without global atomics (per-instance rows + per-Gaussian sum): opt-in, currently
-            # ~5 % slower end to end than the fp32-atomic kernels.  It needs a scratch buffer of
-            # per-instance gradient rows; 0 bytes = not covered for this K.
-            nscratch = int(_lib.hsr_backward_scratch_bytes(P, K, int(R))) if deterministic_backward else 0
+            # Backward scratch, sized by the library for the accumulation mode in force (include/hsr_rasterizer.h):
+            # default: packed per-Gaussian gradient rows (P x stride floats) — halves the atomic requests
+            nscratch = int(_lib.hsr_backward_scratch_bytes(P, K, int(R)))
             scratch = torch.empty(nscratch, dtype=torch.uint8, device=dev) if nscratch else None
             common_tail = (_ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
                            _ptr(scratch), nscratch, int(bool(debug)), stream)

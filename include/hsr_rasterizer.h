@@ -64,6 +64,12 @@ size_t hsr_required_binning_bytes(int num_rendered);
  * experimental backward without global atomics; 0 when that path does not cover K (K > 27).  The reference allocates its
  * backward scratch itself with cudaMalloc/cudaFree per call (rasterizer_impl.cu:673-701); here the caller owns it. */
 size_t hsr_backward_scratch_bytes(int P, int K, int num_rendered);
+/* How the backward accumulates per-Gaussian sums (process-wide; default 0, or HSR_BWD_IMPL=rows|legacy):
+ *   0 packed : fp32 atomics into one 64-byte-aligned scratch row per Gaussian, unpacked by the per-Gaussian
+ *              kernel — about half the atomic requests of the reference's six separate arrays;
+ *   1 rows   : per-instance rows + per-Gaussian sum, no global atomics (experimental, K <= 27);
+ *   2 legacy : atomics straight into the six output arrays, as the reference does; needs no scratch. */
+int hsr_set_backward_mode(int mode);
 
 /* Thread-local text of the last error returned by any hsr_* call on this thread. */
 const char* hsr_last_error(void);

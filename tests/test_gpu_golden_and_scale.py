@@ -119,15 +119,14 @@ def test_rows_backward_matches_oracle():
     from diff_gaussian_rasterization import _C
     from harness import run_oracle
     cam, sc, up = scenes.build(320, 200, 20000, 26, seed=9, kind="slam", scale_mult=2.0, bg=(0.1, 0.2, 0.3))
-    old = _C.deterministic_backward
-    _C.deterministic_backward = True
+    _C.set_backward_mode("rows")
     try:
         o1, g1, _ = run_gpu(cam, sc, up)
         o2, g2, _ = run_gpu(cam, sc, up)
         cam3, sc3, up3 = scenes.build(96, 64, 1200, 40, seed=11)   # K = 40 > 27: falls back to the atomic path
         o3, g3, _ = run_gpu(cam3, sc3, up3)
     finally:
-        _C.deterministic_backward = old
+        _C.set_backward_mode("packed")
     for n in g1:
         assert_close("grad " + n, g1[n], g2[n], rtol=1e-5, atol=1e-6)
     _, go, st = run_oracle(cam, sc, up)
@@ -140,19 +139,20 @@ def test_rows_backward_matches_oracle():
     st3.free()
 
 
+@pytest.mark.parametrize("mode", ["rows", "legacy"])
 @pytest.mark.parametrize("name", ["replica_tree_k26", "scannet_tree_k16", "generic_k5_white_bg", "plain_mask", "huge_splats",
-                                  "culled_behind_camera"])
-def test_parity_deterministic_backward(name):
+                                  "culled_behind_camera", "large_tree_k74"])
+def test_parity_other_accumulation_modes(name, mode):
+    """the default 'packed' mode is what test_gpu_parity.py exercises; these are the other two"""
     from diff_gaussian_rasterization import _C
     from test_gpu_parity import CASES, _compare
     W, H, P, K, kind, sm, semantic, variant, bg, behind = CASES[name]
     cam, sc, up = scenes.build(W, H, P, K, seed=11, kind=kind, scale_mult=sm, bg=bg, behind_frac=behind)
-    old = _C.deterministic_backward
-    _C.deterministic_backward = True
+    _C.set_backward_mode(mode)
     try:
         _compare(cam, sc, up, semantic, variant, None)
     finally:
-        _C.deterministic_backward = old
+        _C.set_backward_mode("packed")
 
 
 @pytest.mark.parametrize("impl", ["mfma"])
