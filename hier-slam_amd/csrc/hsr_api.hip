@@ -238,10 +238,10 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     hsr_carve_bin(bptr, R, &b);
 
     const int end_bit = 32 + (int)higher_msb((uint32_t)T);  // rasterizer_impl.cu:304-312
-    const int passes = (end_bit + 7) / 8;
-    // emit into the buffer pair from which `passes` ping-pong steps end in (keys, vals)
-    uint64_t* emit_k = (passes & 1) ? b.keys_unsorted : b.keys;
-    uint32_t* emit_v = (passes & 1) ? b.vals_unsorted : b.vals;
+    // emit into the buffer pair from which the sort's ping-pong passes end in (keys, vals)
+    const bool emit_sorted = hsr_sort_emit_into_sorted_buffers(end_bit);
+    uint64_t* emit_k = emit_sorted ? b.keys : b.keys_unsorted;
+    uint32_t* emit_v = emit_sorted ? b.vals : b.vals_unsorted;
     {
         StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
         BinState be = b;
@@ -251,13 +251,9 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     }
     HSR_LAUNCH_CHECK(in.debug, stream);
     {
+        // tile-bit radix passes -> tile ranges -> per-tile depth sort (ranges are a by-product of the sort)
         StageTimer tm(HSR_STAGE_FWD_SORT, stream);
-        if ((rc = hsr_launch_sort_pairs(b, R, end_bit, stream)) != HSR_OK) return rc;
-    }
-    HSR_LAUNCH_CHECK(in.debug, stream);
-    {
-        StageTimer tm(HSR_STAGE_FWD_RANGES, stream);
-        if ((rc = hsr_launch_tile_ranges(R, T, b.keys, im.ranges, stream)) != HSR_OK) return rc;
+        if ((rc = hsr_launch_sort_pairs(b, R, end_bit, T, im.ranges, stream)) != HSR_OK) return rc;
     }
     HSR_LAUNCH_CHECK(in.debug, stream);
 

@@ -89,8 +89,11 @@ int hsr_launch_mark_visible(int P, const float* means3D, const float* view, cons
 int hsr_launch_preprocess(const PreprocessArgs& a, GeomState& g, hipStream_t stream);
 int hsr_launch_scan_block_sums(int P, GeomState& g, hipStream_t stream);
 int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, hipStream_t stream);
-int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, hipStream_t stream);
+int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, int T, uint2* ranges, hipStream_t stream);  // also fills ranges
+int hsr_sort_tile_passes(int end_bit);
+bool hsr_sort_emit_into_sorted_buffers(int end_bit);
 int hsr_launch_tile_ranges(int R, int T, const uint64_t* keys, uint2* ranges, hipStream_t stream);
+int hsr_launch_tile_ranges_only(int R, const uint64_t* keys, uint2* ranges, hipStream_t stream);
 
 struct RenderFwdArgs {
     int W, H, K, semantic;

@@ -332,6 +332,12 @@ int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, Geom
     return HSR_OK;
 }
 
+int hsr_launch_tile_ranges_only(int R, const uint64_t* keys, uint2* ranges, hipStream_t stream)
+{
+    if (R > 0) tile_ranges_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, keys, ranges);
+    return HSR_OK;
+}
+
 int hsr_launch_tile_ranges(int R, int T, const uint64_t* keys, uint2* ranges, hipStream_t stream)
 {
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, stream);

@@ -5,7 +5,9 @@
 // STABLE, so instances with equal (tile, depth) keep emission order (ascending Gaussian index).
 // The result is therefore uniquely determined — bit-exact by construction, not by tolerance.
 //
-// Structure per 8-bit pass (HBM-bound integer work; no MFMA):
+// Two phases (hsr_launch_sort_pairs): the radix passes below run over the tile bits only (2 passes at 1200x680
+// instead of 6 over all 44 key bits); the depth order inside each tile comes from tile_sort_kernel in LDS.
+// Structure per pass (HBM-bound integer work; no MFMA):
 //   1. hist:    each block counts the digits of its 4096-item tile in LDS -> hist[digit][block]
 //   2. rowscan: one wave per digit scans that digit's per-block counts; the 256-entry scan across
 //               digits is redone by every scatter block in LDS
@@ -23,7 +25,7 @@ constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096
 
 __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint64_t* __restrict__ keys, int n, int shift,
-                                                                 int nblocks, uint32_t* __restrict__ hist)
+                                                                 uint32_t mask, int nblocks, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
@@ -32,7 +34,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint64_t*
 #pragma unroll 4
     for (int i = 0; i < SORT_ITEMS; i++) {
         const int j = base + i * SORT_THREADS + threadIdx.x;
-        if (j < n) atomicAdd(&h[(uint32_t)(keys[j] >> shift) & 255u], 1u);
+        if (j < n) atomicAdd(&h[(uint32_t)(keys[j] >> shift) & mask], 1u);
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -65,7 +67,7 @@ __global__ void __launch_bounds__(64) sort_rowscan_kernel(uint32_t* __restrict__
 __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64_t* __restrict__ kin,
                                                                     const uint32_t* __restrict__ vin,
                                                                     uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                                    int n, int shift, int nblocks,
+                                                                    int n, int shift, uint32_t mask, int nblocks,
                                                                     const uint32_t* __restrict__ hist_scanned,
                                                                     const uint32_t* __restrict__ totals)
 {
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
     for (int r = 0; r < SORT_ITEMS; r++) {
         const int j = base + r * 64 + lane;
         const bool valid = j < n;
-        const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+        const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
         uint64_t m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -139,7 +141,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
     for (int r = 0; r < SORT_ITEMS; r++) {
         const int j = base + r * 64 + lane;
         if (j < n) {
-            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
             const uint32_t pos = wcnt[w][d] + rank[r];
             kout[pos] = key[r];
             vout[pos] = val[r];
@@ -155,26 +157,168 @@ uint32_t hsr_sort_hist_entries(int R)
     return 256u * (uint32_t)(nblocks > 0 ? nblocks : 1) + 256u;  // per-block counts + 256 digit totals
 }
 
-// Sorts the R pairs on key bits [0, end_bit).  The input must already be in the buffer pair that
-// makes the LAST pass land in (b.keys, b.vals): (keys_unsorted, vals_unsorted) when the pass count
-// is odd, (keys, vals) when it is even — see hsr_sort_input_is_unsorted_buffer().
-int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, hipStream_t stream)
+
+// ---- phase 2: per-tile sort by (depth bits, Gaussian index) ----
+// After the tile passes every tile's entries are contiguous and still in emission order (ascending Gaussian
+// index).  A stable sort on depth inside the tile then equals the reference's stable 64-bit sort; since
+// (depth, index) pairs are unique inside a tile, sorting the composite key (depth << 32) | index with ANY
+// network gives exactly that order.  One workgroup per tile:
+//   n <= TS_MAX : bitonic network on composite keys in LDS (padding = +inf keys);
+//   n  > TS_MAX : block-local stable LSD radix on the 32 depth bits, ping-ponging inside the tile's own segment
+//                 of the two global buffer pairs (segments of different tiles are disjoint).
+constexpr int TS_MAX = 2048;
+
+__device__ __forceinline__ void ts_block_radix(uint64_t* ka, uint32_t* va, uint64_t* kb, uint32_t* vb, int r0, int n,
+                                               uint32_t* hist /*[256]*/, uint32_t (*wcnt)[256])
 {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        hist[t] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) wcnt[i][t] = 0;
+        __syncthreads();
+        for (int i = t; i < n; i += 256) atomicAdd(&hist[(uint32_t)(ka[r0 + i] >> shift) & 255u], 1u);
+        __syncthreads();
+        // exclusive scan of the 256 counts (thread t <-> digit t)
+        {
+            const uint32_t v = hist[t];
+            uint32_t inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t x = __shfl_up(inc, o);
+                if (lane >= o) inc += x;
+            }
+            __shared__ uint32_t wt[4];
+            if (lane == 63) wt[w] = inc;
+            __syncthreads();
+            uint32_t off = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) off += i < w ? wt[i] : 0u;
+            hist[t] = off + inc - v;  // running base of digit t
+        }
+        __syncthreads();
+        for (int c = 0; c < n; c += 256) {
+            const int i = c + t;
+            const bool valid = i < n;
+            const uint64_t k = valid ? ka[r0 + i] : 0ull;
+            const uint32_t v = valid ? va[r0 + i] : 0u;
+            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            uint64_t m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const uint32_t before = __popcll(m & lt);
+            if (valid && before == 0) wcnt[w][d] = (uint32_t)__popcll(m);
+            __syncthreads();
+            if (valid) {
+                uint32_t pos = hist[d] + before;
+#pragma unroll
+                for (int i2 = 0; i2 < 4; i2++) pos += i2 < w ? wcnt[i2][d] : 0u;
+                kb[r0 + pos] = k;
+                vb[r0 + pos] = v;
+            }
+            __syncthreads();
+            hist[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; i2++) wcnt[i2][t] = 0;
+            __syncthreads();
+        }
+        uint64_t* tk = ka; ka = kb; kb = tk;
+        uint32_t* tv = va; va = vb; vb = tv;
+        __threadfence_block();
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
+                                                        uint32_t* __restrict__ vals_alt)
+{
+    __shared__ uint64_t comp[TS_MAX];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wcnt[4][256];
+    const uint2 rg = ranges[blockIdx.x];
+    const int r0 = (int)rg.x, n = (int)(rg.y - rg.x);
+    if (n <= 1) return;
+    const int t = threadIdx.x;
+    if (n > TS_MAX) {
+        ts_block_radix(keys, vals, keys_alt, vals_alt, r0, n, hist, wcnt);  // 4 passes: ends in (keys, vals)
+        return;
+    }
+    int N = 64;
+    while (N < n) N <<= 1;
+    const uint64_t tile_hi = keys[r0] & 0xFFFFFFFF00000000ull;
+    for (int i = t; i < N; i += 256)
+        comp[i] = i < n ? (((keys[r0 + i] & 0xFFFFFFFFull) << 32) | (uint64_t)vals[r0 + i]) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < N / 2; i += 256) {
+                // i-th compare-exchange of this step: partner indices lo < hi differ in bit j
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const uint64_t a = comp[lo], b = comp[hi];
+                if ((a > b) == up) {
+                    comp[lo] = b;
+                    comp[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = t; i < n; i += 256) {
+        const uint64_t c = comp[i];
+        keys[r0 + i] = tile_hi | (c >> 32);
+        vals[r0 + i] = (uint32_t)c;
+    }
+}
+
+// Sorts the R pairs on key bits [0, end_bit) — the contract of the reference's cub::DeviceRadixSort::SortPairs
+// call (rasterizer_impl.cu:307-312) — in two phases: stable LSD passes over the TILE bits only (bits 32..end_bit,
+// at most 8 per pass), then one per-tile sort by depth (tile_sort_kernel).  ranges[] is produced between the two
+// (tile boundaries do not depend on the depth order).  Input must be in the buffer pair from which the tile passes
+// end in (b.keys, b.vals): hsr_sort_emit_into_sorted_buffers() tells the caller which.
+int hsr_sort_tile_passes(int end_bit)
+{
+    const int tile_bits = end_bit - 32;
+    return tile_bits <= 0 ? 0 : (tile_bits + 7) / 8;
+}
+bool hsr_sort_emit_into_sorted_buffers(int end_bit) { return (hsr_sort_tile_passes(end_bit) & 1) == 0; }
+
+int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, int T, uint2* ranges, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, stream);
+    if (e != hipSuccess) {
+        hsr_set_error("hipMemsetAsync(ranges) failed: %s", hipGetErrorString(e));
+        return HSR_ERR_HIP;
+    }
     if (R <= 0) return HSR_OK;
-    const int passes = (end_bit + 7) / 8;
+    const int passes = hsr_sort_tile_passes(end_bit);
+    const int tile_bits = end_bit - 32;
     const int nblocks = (R + SORT_TILE - 1) / SORT_TILE;
     uint32_t* totals = b.hist + (size_t)256 * nblocks;
     uint64_t* ka = (passes & 1) ? b.keys_unsorted : b.keys;
     uint32_t* va = (passes & 1) ? b.vals_unsorted : b.vals;
     uint64_t* kb = (passes & 1) ? b.keys : b.keys_unsorted;
     uint32_t* vb = (passes & 1) ? b.vals : b.vals_unsorted;
+    const int bits_per_pass = passes ? (tile_bits + passes - 1) / passes : 0;
     for (int p = 0; p < passes; p++) {
-        const int shift = 8 * p;
-        sort_hist_kernel<<<nblocks, SORT_THREADS, 0, stream>>>(ka, R, shift, nblocks, b.hist);
+        const int shift = 32 + bits_per_pass * p;
+        const int bits = min(bits_per_pass, end_bit - shift);
+        const uint32_t mask = (1u << bits) - 1u;
+        sort_hist_kernel<<<nblocks, SORT_THREADS, 0, stream>>>(ka, R, shift, mask, nblocks, b.hist);
         sort_rowscan_kernel<<<256, 64, 0, stream>>>(b.hist, nblocks, totals);
-        sort_scatter_kernel<<<nblocks, SORT_THREADS, 0, stream>>>(ka, va, kb, vb, R, shift, nblocks, b.hist, totals);
+        sort_scatter_kernel<<<nblocks, SORT_THREADS, 0, stream>>>(ka, va, kb, vb, R, shift, mask, nblocks, b.hist, totals);
         uint64_t* tk = ka; ka = kb; kb = tk;
         uint32_t* tv = va; va = vb; vb = tv;
     }
+    // (b.keys, b.vals) now hold the instances grouped by tile, in emission order inside each tile
+    hsr_launch_tile_ranges_only(R, b.keys, ranges, stream);
+    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted);
     return HSR_OK;
 }

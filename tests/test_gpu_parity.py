@@ -25,6 +25,8 @@ CASES = {
     "culled_behind_camera": (96, 64, 1500, 26, "aniso", 2.0, True, "sr", (0, 0, 0), 0.4),
     "huge_splats": (96, 64, 300, 26, "aniso", 40.0, True, "sr", (0, 0, 0), 0.0),  # splats covering the whole screen
     "semantic_k0": (64, 48, 500, 0, "aniso", 2.0, True, "sr", (0, 0, 0), 0.0),
+    # > 2048 entries in every tile: the per-tile sort's block-radix fallback (and many staging batches per tile)
+    "deep_tiles_3000": (64, 48, 3000, 16, "aniso", 40.0, True, "sr", (0, 0, 0), 0.0),
 }
 
 
