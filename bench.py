@@ -108,10 +108,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0, gloo instead of RCCL
+    share_gpu = os.environ.get("HSR_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("HSR_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", 0 if share_gpu else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer_semantic, _C

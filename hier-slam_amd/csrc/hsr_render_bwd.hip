@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
         tgt_stride = a.grow_stride;
         if (BASE) {
             if (myv < 6) tgt_base = a.grow + myv;                                   // mean2D.xy, conic.xyw, opacity (total)
-            else if (myv < 9) tgt_base = a.grow + 8 + (myv - 6);                    // rgb
+            else if (myv < 9) tgt_base = a.grow + hsr_grow_direct0(a.K) + (myv - 6); // rgb
             else if (myv == 9) tgt_base = a.grow + 6;                               // depth (total)
             else if (myv < NV && c0 + (myv - 10) < a.K) tgt_base = a.grow + HSR_GROW_SEM0 + c0 + (myv - 10);
         } else if (myv < NV && c0 + myv < a.K) {

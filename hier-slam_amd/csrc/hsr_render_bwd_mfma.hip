@@ -142,10 +142,10 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
             const int ch = 16 * g + (lane & 15);
             mf_base[g] = nullptr;
             mf_stride[g] = 0;
-            if (a.grow) {  // packed row: semantics from column 16, rgb / depth / opacity (direct parts) at 8..12
+            if (a.grow) {  // packed row: semantics from column 16, direct sums right behind them
                 mf_stride[g] = a.grow_stride;
                 if (ch < KC) { if (ch < a.K) mf_base[g] = a.grow + HSR_GROW_SEM0 + ch; }
-                else if (ch < KC + 5) mf_base[g] = a.grow + 8 + (ch - KC);
+                else if (ch < KC + 5) mf_base[g] = a.grow + hsr_grow_direct0(a.K) + (ch - KC);
             } else if (ch < KC) { if (ch < a.K) { mf_base[g] = a.dL_dsemantics + ch; mf_stride[g] = a.K; } }
             else if (ch < KC + 3) { mf_base[g] = a.dL_dcolor + (ch - KC); mf_stride[g] = 3; }
             else if (ch == KC + 3) { mf_base[g] = a.dL_ddepth; mf_stride[g] = 1; }

@@ -112,8 +112,11 @@ __device__ __forceinline__ int build_flat_list(int wv, int lane, const uint8_t (
 // dL_ddepths, dL_dsemantics: rasterize_points.cu:378-388), so one (tile, Gaussian) update touches six cache lines.
 // Float atomics on MI355X execute at the memory side in 64-byte requests at a fixed chip-wide rate, so the
 // number of LINES touched is what an update costs.  Packed layout, one row per Gaussian, 64-byte aligned:
-//   col 0,1 mean2D.xy | 2,3,4 conic.xyw | 5 opacity (alpha path, or total) | 6 depth (median part, or total)
-//   col 8,9,10 rgb | 11 depth (direct part) | 12 opacity (direct part) | 16 + c semantic channel c
+//   line 0 : col 0,1 mean2D.xy | 2,3,4 conic.xyw | 5 opacity (alpha path, or total) | 6 depth (median part, or total)
+//   line 1+: col 16 + c semantic channel c (c < K), then the "direct" sums at col 16 + K + {0,1,2} rgb,
+//            + 3 depth (direct part), + 4 opacity (direct part) — directly behind the semantics so that the
+//            matrix-core kernel's second 16-channel group (sem 16..25, r, g, b, depth, opacity at K = 26) is ONE line.
 // preprocess_backward_kernel unpacks the row into the reference's arrays.
 #define HSR_GROW_SEM0 16
-__host__ __device__ inline int hsr_grow_stride(int K) { return 16 + 16 * ((K + 15) / 16); }
+__host__ __device__ inline int hsr_grow_stride(int K) { return 16 + 16 * ((K + 5 + 15) / 16); }
+__host__ __device__ inline int hsr_grow_direct0(int K) { return HSR_GROW_SEM0 + K; }
