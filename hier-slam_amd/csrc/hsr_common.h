@@ -114,6 +114,7 @@ struct RenderFwdArgs {
     float* out_mask;  // non-semantic variant only
 };
 int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream);
+int hsr_launch_render_forward_mfma(const RenderFwdArgs& a, hipStream_t stream);  // returns #semantic channels produced
 
 struct RenderBwdArgs {
     int W, H, K, semantic, P;
