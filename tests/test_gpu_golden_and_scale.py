@@ -156,8 +156,9 @@ def test_parity_other_accumulation_modes(name, mode):
 
 
 @pytest.mark.parametrize("impl", ["mfma"])
-def test_parity_alternate_atomic_kernel(impl):
-    """the MFMA-assisted atomic kernel is selected per process (HSR_BWD_IMPL): run one parity case in a child"""
+def test_parity_matrix_core_kernels(impl):
+    """the MFMA-assisted forward / backward kernels are selected per process (HSR_FWD_IMPL / HSR_BWD_IMPL): run parity
+    cases in a child (K = 26 fused, K = 74 = matrix-core chunk + VALU chunks)"""
     import subprocess
     import sys
     code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
@@ -165,7 +166,7 @@ def test_parity_alternate_atomic_kernel(impl):
             "_compare(cam,sc,up,sem,var,None);"
             "W,H,P,K,kind,sm,sem,var,bg,beh=CASES['large_tree_k74'];cam,sc,up=scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg);"
             "_compare(cam,sc,up,sem,var,None);print('ok')")
-    env = dict(os.environ, HSR_BWD_IMPL=impl)
+    env = dict(os.environ, HSR_BWD_IMPL=impl, HSR_FWD_IMPL=impl)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
