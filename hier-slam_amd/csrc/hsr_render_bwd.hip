@@ -24,6 +24,22 @@
 
 namespace {
 
+// out[c] = w * in[c] with v_pk_mul_f32 (two products per VALU issue slot; the kernel is VALU-issue bound)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ void mul_packed(float w, const float* in, float* out)
+{
+    const f32x2 w2 = {w, w};
+#pragma unroll
+    for (int c = 0; c + 1 < N; c += 2) {
+        const f32x2 a = {in[c], in[c + 1]};
+        const f32x2 r = a * w2;
+        out[c] = r.x;
+        out[c + 1] = r.y;
+    }
+    if (N & 1) out[N - 1] = w * in[N - 1];
+}
+
 // BASE: this launch produces the 10 geometric/colour sums (and the first KC semantic channels);
 // !BASE: semantic channels [c0, c0+KC) only (generic-K chunking).
 template <int KC, bool BASE>
@@ -224,11 +240,9 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
                         last_h = h;
                         last_alpha = alpha;
                     }
-#pragma unroll
-                    for (int c = 0; c < KC; c++) v[10 + c] = w * dsem[c];
+                    mul_packed<KC>(w, dsem, v + 10);
                 } else {
-#pragma unroll
-                    for (int c = 0; c < KC; c++) v[c] = w * dsem[c];
+                    mul_packed<KC>(w, dsem, v);
                 }
                 if (active) T = test_T;
 
