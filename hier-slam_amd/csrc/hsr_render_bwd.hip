@@ -263,14 +263,11 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
     const dim3 grid(tiles), block(256);
-    // default: the all-VALU kernels below.  HSR_BWD_IMPL=mfma selects the matrix-core path
-    // (hsr_render_bwd_mfma.hip: base sums + the first 27 semantic channels, VALU chunks for the rest); it issues
-    // 45 % fewer VALU instructions but is currently ~5 % slower end to end (atomic request rate).
-    static const bool use_mfma = getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "mfma");
-    if (use_mfma) {
+    // default for K <= 27: the matrix-core kernel (hsr_render_bwd_mfma.hip), half the VALU instructions of the
+    // all-VALU kernels below, which serve K > 27 and HSR_BWD_IMPL=valu (A/B timing, tests).
+    static const bool use_mfma = !(getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "valu"));
+    if (use_mfma && (a.semantic ? a.K : 0) <= 27) {  // one matrix-core launch covers the base sums + K <= 27 channels
         hsr_launch_render_backward_mfma(a, stream);
-        const int K = a.semantic ? a.K : 0;
-        for (int c0 = 27; c0 < K; c0 += 32) render_bwd_kernel<32, false><<<grid, block, 0, stream>>>(a, c0);
         return HSR_OK;
     }
     if (!a.semantic || a.K == 0) {

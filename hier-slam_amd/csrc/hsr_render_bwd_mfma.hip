@@ -47,6 +47,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
     __shared__ int s_wmax[4];
     __shared__ float s_panel[4][MF_PANEL];
     __shared__ int s_slot_id[4][MF_SLOTS];
+    __shared__ int s_prev_id[4][MF_SLOTS];
+    __shared__ float s_u7[4][MF_SLOTS * 8];
 
     const int tile = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -79,26 +81,35 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
         dpo = a.dL_dpix_opacity[pix_id];
     }
     float Breg[NG][16];
+    {
+        // issue every global load of this lane's upstream gradients first (independent, one wait), THEN go through
+        // LDS: a load -> ds_write pair per channel would serialise 32 global round trips in the prologue
+        float gv[NG][16];
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        // channels [16g, 16g+16) of this lane's pixel -> panel[pixel][c] (row stride 17)
+        for (int g = 0; g < NG; g++)
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const int ch = 16 * g + c;
-            float v = 0.f;
-            if (ch < KC) {
-                if (inside && ch < a.K) v = a.dL_dpix_sem[(size_t)ch * N + pix_id];
-            } else if (ch == KC) v = dpx0;
-            else if (ch == KC + 1) v = dpx1;
-            else if (ch == KC + 2) v = dpx2;
-            else if (ch == KC + 3) v = dpd;
-            else if (ch == KC + 4) v = dpo;
-            panel[lane * 17 + c] = v;
+            for (int c = 0; c < 16; c++) {
+                const int ch = 16 * g + c;
+                float v = 0.f;
+                if (ch < KC) {
+                    if (inside && ch < a.K) v = a.dL_dpix_sem[(size_t)ch * N + pix_id];
+                } else if (ch == KC) v = dpx0;
+                else if (ch == KC + 1) v = dpx1;
+                else if (ch == KC + 2) v = dpx2;
+                else if (ch == KC + 3) v = dpd;
+                else if (ch == KC + 4) v = dpo;
+                gv[g][c] = v;
+            }
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            // channels [16g, 16g+16) of this lane's pixel -> panel[pixel][c] (row stride 17), read back transposed
+#pragma unroll
+            for (int c = 0; c < 16; c++) panel[lane * 17 + c] = gv[g][c];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) Breg[g][m] = panel[(4 * m + (lane >> 4)) * 17 + (lane & 15)];
+            __syncthreads();
         }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < 16; m++) Breg[g][m] = panel[(4 * m + (lane >> 4)) * 17 + (lane & 15)];
-        __syncthreads();
     }
     const int hi_all = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
 
@@ -116,7 +127,21 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
     else if (myv < 5) { tgt_base = a.dL_dconic + (myv == 4 ? 3 : myv - 2); tgt_stride = 4; }
     else if (myv == 5) { tgt_base = a.dL_dopacity; tgt_stride = 1; }
     else if (myv == 6) { tgt_base = a.dL_ddepth; tgt_stride = 1; }
-    int nslot = 0;  // wave-uniform: accepted splats waiting in the panel
+    int nslot = 0;   // wave-uniform: accepted splats waiting in the panel
+    int prev_n = 0;  // wave-uniform: finished rows of the previous group still parked in the panel (packed mode)
+    const bool packed = a.grow != nullptr;
+    // packed mode: which packed-row column this lane emits, if any (cols 0..6 | 16..16+K-1 | 16+K..16+K+4)
+    const bool emit_lane = packed && lane < a.grow_stride && (lane < 7 || (lane >= HSR_GROW_SEM0 && lane < HSR_GROW_SEM0 + a.K + 5));
+
+    // Packed mode, deferred emission: a finished group's 16 rows stay in the panel (row s in the 66-float panel
+    // row s, which the MFMAs have already consumed) and row s is added to global memory — ONE atomic
+    // wave-instruction covering the Gaussian's whole packed row — just before the next group's s-th splat
+    // overwrites that panel row.  Atomics are thereby spaced one per accepted splat instead of bursts of 24.
+    auto emit_row = [&](int srow) {
+        const float val = panel[srow * MF_STRIDE + lane];
+        if (emit_lane && !(a.debug_flags & 1))
+            atomicAdd(a.grow + (size_t)s_prev_id[wv][srow] * a.grow_stride + lane, val);
+    };
     auto flush = [&]() {
         if (a.debug_flags & 2) {  // timing experiment: no MFMA / no flush atomics
             nslot = 0;
@@ -132,9 +157,33 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
 #pragma unroll
             for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Breg[g][m], acc[g], 0, 0, 0);
         }
-        // D[row = 4*(lane>>4) + r][col = lane&15]: row = panel slot, col = channel within the group.
-        // Atomic targets of the columns this lane holds (channel 16g + (lane & 15)) are recomputed here,
-        // once per 16 splats, instead of living in registers across the blend loop.
+        // D[row = 4*(lane>>4) + r][col = lane&15]: row = panel slot, col = channel within the group
+        if (packed) {
+            // park the finished rows in the panel, in packed-row column order
+            int colg[NG];
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int ch = 16 * g + (lane & 15);
+                colg[g] = ch < KC ? (ch < a.K ? HSR_GROW_SEM0 + ch : -1) : (ch < KC + 5 ? hsr_grow_direct0(a.K) + (ch - KC) : -1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int slot = 4 * (lane >> 4) + r;
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+                    if (colg[g] >= 0) panel[slot * MF_STRIDE + colg[g]] = acc[g][r];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {  // the 7 butterfly sums of each slot -> columns 0..6
+                const int slot = 8 * h + (lane >> 3), vv = lane & 7;
+                if (vv < 7) panel[slot * MF_STRIDE + vv] = s_u7[wv][slot * 8 + vv];
+            }
+            if (lane < MF_SLOTS) s_prev_id[wv][lane] = s_slot_id[wv][lane];
+            prev_n = nslot;
+            nslot = 0;
+            return;
+        }
+        // legacy arrays: atomic targets of the columns this lane holds, recomputed once per 16 splats
         float* mf_base[NG];
         int mf_stride[NG];
 #pragma unroll
@@ -142,11 +191,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
             const int ch = 16 * g + (lane & 15);
             mf_base[g] = nullptr;
             mf_stride[g] = 0;
-            if (a.grow) {  // packed row: semantics from column 16, direct sums right behind them
-                mf_stride[g] = a.grow_stride;
-                if (ch < KC) { if (ch < a.K) mf_base[g] = a.grow + HSR_GROW_SEM0 + ch; }
-                else if (ch < KC + 5) mf_base[g] = a.grow + hsr_grow_direct0(a.K) + (ch - KC);
-            } else if (ch < KC) { if (ch < a.K) { mf_base[g] = a.dL_dsemantics + ch; mf_stride[g] = a.K; } }
+            if (ch < KC) { if (ch < a.K) { mf_base[g] = a.dL_dsemantics + ch; mf_stride[g] = a.K; } }
             else if (ch < KC + 3) { mf_base[g] = a.dL_dcolor + (ch - KC); mf_stride[g] = 3; }
             else if (ch == KC + 3) { mf_base[g] = a.dL_ddepth; mf_stride[g] = 1; }
             else if (ch == KC + 4) { mf_base[g] = a.dL_dopacity; mf_stride[g] = 1; }
@@ -227,6 +272,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
                     const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
                     const float test_T = T * inv_one_m_a;
                     const float w = active ? alpha * test_T : 0.f;
+                    // packed mode: the previous group's row parked in this panel row leaves now
+                    if (nslot < prev_n) emit_row(nslot);
                     // direct sums go through the panel -> MFMA
                     panel[nslot * MF_STRIDE + lane] = w;
                     if (lane == 0) s_slot_id[wv][nslot] = s_id[j];
@@ -262,7 +309,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
                         continue;
                     }
                     const float total = wave_reduce_transpose<NV>(v, lane);
-                    if (a.debug_flags & 1) {
+                    if (packed) {
+                        if (myv < NV) s_u7[wv][nslot * 8 + myv] = total;  // joins its row at the flush
+                    } else if (a.debug_flags & 1) {
                         asm volatile("" ::"v"(total));
                     } else if (tgt_base) {
                         atomicAdd(tgt_base + (size_t)s_id[j] * tgt_stride, total);
@@ -273,7 +322,16 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
             }
         }
     }
-    if (nslot > 0) flush();
+    if (packed) {
+        for (int sr = nslot; sr < prev_n; sr++) emit_row(sr);  // rows of the previous group not displaced yet
+        prev_n = 0;
+        if (nslot > 0) {
+            flush();
+            for (int sr = 0; sr < prev_n; sr++) emit_row(sr);
+        }
+    } else if (nslot > 0) {
+        flush();
+    }
 }
 
 }  // namespace

@@ -155,17 +155,17 @@ def test_parity_other_accumulation_modes(name, mode):
         _C.set_backward_mode("packed")
 
 
-@pytest.mark.parametrize("impl", ["mfma"])
-def test_parity_matrix_core_kernels(impl):
-    """the MFMA-assisted forward / backward kernels are selected per process (HSR_FWD_IMPL / HSR_BWD_IMPL): run parity
-    cases in a child (K = 26 fused, K = 74 = matrix-core chunk + VALU chunks)"""
+@pytest.mark.parametrize("impl", ["mfma", "valu"])
+def test_parity_alternate_kernels(impl):
+    """kernel families are selected per process (HSR_FWD_IMPL / HSR_BWD_IMPL = mfma | valu; defaults: VALU forward,
+    matrix-core backward for K <= 27): run parity cases of the non-default combination in a child process"""
     import subprocess
     import sys
     code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
             "W,H,P,K,kind,sm,sem,var,bg,beh=CASES['replica_tree_k26'];cam,sc,up=scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg);"
             "_compare(cam,sc,up,sem,var,None);"
-            "W,H,P,K,kind,sm,sem,var,bg,beh=CASES['large_tree_k74'];cam,sc,up=scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg);"
-            "_compare(cam,sc,up,sem,var,None);print('ok')")
+            "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
+            "for n in ('scannet_tree_k16','generic_k5_white_bg','plain_mask','huge_splats','deep_tiles_3000','large_tree_k74')];print('ok')")
     env = dict(os.environ, HSR_BWD_IMPL=impl, HSR_FWD_IMPL=impl)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
