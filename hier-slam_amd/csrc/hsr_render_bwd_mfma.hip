@@ -61,25 +61,29 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
     const uint2 range = a.ranges[tile];
     float* panel = s_panel[wv];
 
-    const float T_final = inside ? a.final_T[pix_id] : 0.f;
+    // Every prologue load is unconditional (out-of-image lanes read pixel 0 and are zeroed afterwards) and
+    // issued before anything consumes one: a per-lane guard makes hipcc branch around each load and wait for it
+    // separately (38 serialised global round trips per wave otherwise).
+    const size_t pix_ld = inside ? pix_id : 0;
+    const float inm = inside ? 1.f : 0.f;
+    const float T_final_ld = a.final_T[pix_ld];
+    const int last_contributor_ld = (int)a.n_contrib[pix_ld];
+    float dpx0 = a.dL_dpix[pix_ld], dpx1 = a.dL_dpix[N + pix_ld], dpx2 = a.dL_dpix[2 * N + pix_ld];
+    float dpd = a.dL_dpix_depth[pix_ld], dpm = a.dL_dpix_median[pix_ld], dpo = a.dL_dpix_opacity[pix_ld];
+    float semv[KC > 0 ? KC : 1];
+#pragma unroll
+    for (int c = 0; c < KC; c++) semv[c] = a.dL_dpix_sem[(size_t)min(c, a.K - 1) * N + pix_ld];
+    dpx0 *= inm; dpx1 *= inm; dpx2 *= inm; dpd *= inm; dpm *= inm; dpo *= inm;
+    const float T_final = T_final_ld * inm;
     float T = T_final;
-    const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
+    const int last_contributor = inside ? last_contributor_ld : 0;
 
     int wmax = last_contributor;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
     if (lane == 0) s_wmax[wv] = wmax;
 
-    // ---- upstream gradients of this lane's pixel, then the MFMA B operand (G transposed through LDS) ----
-    float dpx0 = 0, dpx1 = 0, dpx2 = 0, dpd = 0, dpm = 0, dpo = 0;
-    if (inside) {
-        dpx0 = a.dL_dpix[pix_id];
-        dpx1 = a.dL_dpix[N + pix_id];
-        dpx2 = a.dL_dpix[2 * N + pix_id];
-        dpd = a.dL_dpix_depth[pix_id];
-        dpm = a.dL_dpix_median[pix_id];
-        dpo = a.dL_dpix_opacity[pix_id];
-    }
+    // ---- the MFMA B operand: G transposed through LDS ----
     float Breg[NG][16];
     {
         // issue every global load of this lane's upstream gradients first (independent, one wait), THEN go through
@@ -92,7 +96,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
                 const int ch = 16 * g + c;
                 float v = 0.f;
                 if (ch < KC) {
-                    if (inside && ch < a.K) v = a.dL_dpix_sem[(size_t)ch * N + pix_id];
+                    v = (ch < a.K) ? semv[ch < KC ? ch : 0] * inm : 0.f;
                 } else if (ch == KC) v = dpx0;
                 else if (ch == KC + 1) v = dpx1;
                 else if (ch == KC + 2) v = dpx2;
