@@ -247,7 +247,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
         BinState be = b;
         be.keys_unsorted = emit_k;
         be.vals_unsorted = emit_v;
-        hsr_launch_duplicate(P, radii, tiles_x, tiles_y, g, be, stream);
+        hsr_launch_duplicate(P, radii, tiles_x, tiles_y, g, be, im.ranges, stream);
     }
     HSR_LAUNCH_CHECK(in.debug, stream);
     {

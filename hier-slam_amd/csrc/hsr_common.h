@@ -88,7 +88,8 @@ int hsr_launch_mark_visible(int P, const float* means3D, const float* view, cons
                             hipStream_t stream);
 int hsr_launch_preprocess(const PreprocessArgs& a, GeomState& g, hipStream_t stream);
 int hsr_launch_scan_block_sums(int P, GeomState& g, hipStream_t stream);
-int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, hipStream_t stream);
+int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, uint2* ranges,
+                         hipStream_t stream);  // also zeroes ranges[0, tiles)
 int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, int T, uint2* ranges, hipStream_t stream);  // also fills ranges
 int hsr_sort_tile_passes(int end_bit);
 bool hsr_sort_emit_into_sorted_buffers(int end_bit);

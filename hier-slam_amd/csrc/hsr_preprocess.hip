@@ -261,10 +261,14 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblk, uint32_
 // rasterizer_impl.cu:281) and emits one (tile|depth, id) pair per touched tile, row-major over the
 // rect exactly like the reference's duplicateWithKeys (rasterizer_impl.cu:70-111).
 __global__ void __launch_bounds__(256) duplicate_kernel(int P, const int* __restrict__ radii, int tiles_x, int tiles_y,
-                                                        GeomState g, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                        GeomState g, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        uint2* __restrict__ ranges)
 {
     __shared__ uint32_t smem[256 / 64 + 1];
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    // the reference's cudaMemset of the tile ranges (rasterizer_impl.cu:314) rides along here: ranges are next
+    // written by tile_ranges_kernel, several launches later
+    for (int i = idx; i < tiles_x * tiles_y; i += gridDim.x * 256) ranges[i] = make_uint2(0u, 0u);
     const uint32_t touched = idx < P ? g.tiles_touched[idx] : 0;
     uint32_t total;
     uint32_t off = block_exclusive_scan<256>(touched, smem, total) + g.block_sums[blockIdx.x];
@@ -326,9 +330,10 @@ int hsr_launch_scan_block_sums(int P, GeomState& g, hipStream_t stream)
     return HSR_OK;
 }
 
-int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, hipStream_t stream)
+int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, uint2* ranges,
+                         hipStream_t stream)
 {
-    duplicate_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, radii, tiles_x, tiles_y, g, b.keys_unsorted, b.vals_unsorted);
+    duplicate_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, radii, tiles_x, tiles_y, g, b.keys_unsorted, b.vals_unsorted, ranges);
     return HSR_OK;
 }
 

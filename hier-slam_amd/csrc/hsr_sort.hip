@@ -292,11 +292,7 @@ bool hsr_sort_emit_into_sorted_buffers(int end_bit) { return (hsr_sort_tile_pass
 
 int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, int T, uint2* ranges, hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, stream);
-    if (e != hipSuccess) {
-        hsr_set_error("hipMemsetAsync(ranges) failed: %s", hipGetErrorString(e));
-        return HSR_ERR_HIP;
-    }
+    // ranges[] was zeroed by the key-emission kernel (hsr_launch_duplicate)
     if (R <= 0) return HSR_OK;
     const int passes = hsr_sort_tile_passes(end_bit);
     const int tile_bits = end_bit - 32;
