@@ -10,10 +10,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "hsr_rasterizer.h")
+HEADERS = [HEADER, os.path.join(ROOT, "include", "hsr_frame_prep.h")]
 
 
 def _prototypes():
-    src = open(HEADER).read()
+    src = "\n".join(open(h).read() for h in HEADERS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(hsr_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
@@ -28,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     protos = _prototypes()
     assert {"hsr_forward", "hsr_forward_semantic", "hsr_backward", "hsr_backward_semantic", "hsr_mark_visible",
             "hsr_required_geometry_bytes", "hsr_required_image_bytes", "hsr_required_binning_bytes", "hsr_last_error",
-            "hsr_version", "hsr_get_state_layout", "hsr_profile_enable", "hsr_profile_read", "hsr_stage_name"} <= set(protos)
+            "hsr_version", "hsr_get_state_layout", "hsr_profile_enable", "hsr_profile_read", "hsr_stage_name",
+            "hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes"} <= set(protos)
     lib = C.CDLL(_C._LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), "libhsr_rast.so does not export %s" % name
@@ -40,6 +42,10 @@ def test_ctypes_signatures_match_header():
     for name in ("hsr_forward", "hsr_forward_semantic", "hsr_backward", "hsr_backward_semantic", "hsr_mark_visible",
                  "hsr_get_state_layout", "hsr_required_binning_bytes", "hsr_required_image_bytes"):
         fn = getattr(_C._lib, name)
+        assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
+    from hsr_utils import slam_helpers
+    for name in ("hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes"):
+        fn = getattr(slam_helpers._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
 
 
@@ -69,6 +75,13 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"invalid sizes" in lib.hsr_last_error()
     rc = lib.hsr_mark_visible(-1, null, null, null, null, null)
     assert rc == -1
+    from hsr_utils import slam_helpers  # sets the argtypes of the frame-prep entry points
+    assert slam_helpers._lib.hsr_frame_prep_scratch_bytes(0) > 0
+    assert slam_helpers._lib.hsr_frame_prep_scratch_bytes(10 ** 6) >= (10 ** 6 // 1024) * 64
+    rc = lib.hsr_frame_prep_forward(10, 2, 0, 0, *([null] * 6), 1, 0, *([null] * 8))
+    assert rc == -1 and b"log_scales must be" in lib.hsr_last_error()
+    rc = lib.hsr_frame_prep_backward(0, 1, 0, 0, *([null] * 6), 1, 5, *([null] * 14), 0, null)
+    assert rc == -1 and b"time_idx" in lib.hsr_last_error()
 
 
 def test_no_cpu_fallback_and_reference_error_messages():
