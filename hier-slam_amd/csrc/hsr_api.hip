@@ -263,7 +263,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb; ra.semantics = in.semantics;
     ra.final_T = im.final_T; ra.n_contrib = im.n_contrib;
     ra.out_color = in.out_color; ra.out_semantic = in.out_semantic; ra.out_depth = in.out_depth;
-    ra.out_median_depth = in.out_median; ra.out_opacity = in.out_opacity; ra.out_mask = in.out_mask;
+    ra.out_median_depth = in.out_median; ra.out_opacity = in.out_opacity; ra.out_mask = in.out_mask; ra.debug_flags = 0;
     if (!in.semantic && !in.out_mask) {
         hsr_set_error("out_mask is NULL");
         return HSR_ERR_INVALID_ARGUMENT;

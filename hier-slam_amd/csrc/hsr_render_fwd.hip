@@ -233,6 +233,12 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
         render_fwd_kernel<0, true, true, false><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;
     }
+    // wide trees (29 <= K <= 124): matrix-core accumulation (hsr_render_fwd_wide.hip) unless HSR_FWD_IMPL=valu asks for
+    // the per-lane accumulators below.  Measured at 500k Gaussians, 1200x680 (tools/kcompare.sh), wide vs per-lane:
+    // K=33 0.41/0.59 ms, 60 0.43/0.62, 90 0.62/0.96, 102 0.70/1.16, 124 0.71/1.24 — and K=74 0.61/0.54, the one
+    // width whose fused per-lane instantiation (222 registers, 2 waves/SIMD) still wins, so it keeps it.
+    static const bool force_valu = getenv("HSR_FWD_IMPL") && !strcmp(getenv("HSR_FWD_IMPL"), "valu");
+    if (!force_valu && a.K != 74 && hsr_launch_render_forward_wide(a, stream)) return HSR_OK;
     switch (a.K) {
     case 0: render_fwd_kernel<0, true, false, false><<<grid, block, 0, stream>>>(a, 0); break;
     case 16: render_fwd_kernel<16, true, false, true><<<grid, block, 0, stream>>>(a, 0); break;   // ScanNet tree
