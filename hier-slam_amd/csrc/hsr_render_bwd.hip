@@ -270,6 +270,10 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
         hsr_launch_render_backward_mfma(a, stream);
         return HSR_OK;
     }
+    if (use_mfma && a.semantic && a.K > 27) {  // wide trees: matrix-core passes of <= 64 channels (hsr_render_bwd_wide.hip)
+        hsr_launch_render_backward_wide(a, stream);
+        return HSR_OK;
+    }
     if (!a.semantic || a.K == 0) {
         render_bwd_kernel<0, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;

@@ -24,7 +24,7 @@ CASES = {
     "odd_k75_ragged": (100, 70, 1500, 75, "aniso", 2.5, True, "sr", (0.3, 0.2, 0.1), 0.0),
     "k124_widest_single_pass": (64, 48, 600, 124, "slam", 3.0, True, "sr", (0, 0, 0), 0.0),
     "k130_chunked": (64, 48, 600, 130, "slam", 3.0, True, "sr", (0, 0, 0), 0.0),
-    "wide_deep_tiles_k74": (64, 48, 1500, 74, "aniso", 40.0, True, "sr", (0, 0, 0), 0.0),  # many batches, early termination
+    "wide_deep_tiles_k76": (64, 48, 1500, 76, "aniso", 40.0, True, "sr", (0, 0, 0), 0.0),  # many batches, early termination
     "plain_mask": (144, 96, 2500, 0, "aniso", 2.0, False, "sr", (0, 0, 0), 0.0),
     "plain_cov3d": (96, 80, 1500, 0, "aniso", 2.0, False, "cov", (0, 0, 0), 0.0),
     "culled_behind_camera": (96, 64, 1500, 26, "aniso", 2.0, True, "sr", (0, 0, 0), 0.4),
