@@ -1,0 +1,183 @@
+"""Loss heads on the rendered maps with the reference's names, each fused into one streaming HIP pass that produces the
+value and the gradient together (include/hsr_losses.h).
+
+    l1_loss_v1(x, y)                                   utils/slam_helpers.py:5-6
+    calc_ssim(img1, img2, window_size=11, size_average=True)      utils/slam_external.py:66-97
+    masked_l1(pred, gt, mask, reduction)               torch.abs(gt - pred)[mask].sum() | .mean()   scripts/hierslam.py:921-937
+    tree_cross_entropy(im_semantic, labels, num_semantic, weights=None)
+                                                       sum over levels of CrossEntropyLoss(transfer_tree_rendered_labelmap(
+                                                       im_semantic, i_level, dataset), labels[i_level])   scripts/hierslam.py:963-974
+    cross_entropy_planar(logits, labels)               CrossEntropyLoss on [C,H,W] logits (flat classes, :947-954; leaf MLP, :976-983)
+
+`mapping_image_loss(im, gt)` is the reference's mapping colour term 0.8*L1 + 0.2*(1 - SSIM) (scripts/hierslam.py:939).
+Gradients flow to the FIRST argument only (the rendered map); the ground truth is data.  There is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from diff_gaussian_rasterization import _C as _glue
+
+_lib = _glue._lib
+_vp, _ci, _sz = C.c_void_p, C.c_int, C.c_size_t
+_lib.hsr_loss_scratch_bytes.restype = _sz
+_lib.hsr_loss_scratch_bytes.argtypes = [_ci, _ci, _ci]
+_lib.hsr_loss_l1.restype = _ci
+_lib.hsr_loss_l1.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _sz, _vp]
+_lib.hsr_loss_ssim.restype = _ci
+_lib.hsr_loss_ssim.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+_lib.hsr_loss_tree_ce.restype = _ci
+_lib.hsr_loss_tree_ce.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), C.POINTER(C.c_float), _vp, _vp, _ci, _vp, _vp, _vp, _sz, _vp]
+
+SUM, MEAN = 0, 1
+_weight_cache = {}
+
+
+def _chw(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("hsr_utils.losses: %s must live on a HIP device (got %s); there is no CPU path" % (what, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("hsr_utils.losses: %s must be float32 (got %s)" % (what, t.dtype))
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() != 3:
+        raise RuntimeError("hsr_utils.losses: %s must be [C,H,W] or [H,W]" % what)
+    return t.contiguous()
+
+
+def _scratch(ch, H, W, dev):
+    return torch.empty(int(_lib.hsr_loss_scratch_bytes(ch, H, W)), dtype=torch.uint8, device=dev)
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, mask, reduction):
+        shape = pred.shape
+        p, g = _chw(pred, "pred"), _chw(gt.detach(), "gt")
+        if p.shape != g.shape:
+            raise RuntimeError("hsr_utils.losses: pred %s and gt %s differ in shape" % (tuple(shape), tuple(gt.shape)))
+        Cc, H, W = p.shape
+        dev = p.device
+        m = None
+        if mask is not None:
+            m = mask.reshape(-1, H, W)
+            if m.shape[0] != 1:
+                raise RuntimeError("hsr_utils.losses: mask must be [H,W] or [1,H,W] (it is tiled over the channels)")
+            m = (m if m.dtype == torch.bool else m != 0).to(torch.uint8).contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(p) if pred.requires_grad else None
+        sc = _scratch(Cc, H, W, dev)
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_l1(Cc, H, W, p.data_ptr(), g.data_ptr(), None if m is None else m.data_ptr(), int(reduction),
+                                  out.data_ptr(), None if grad is None else grad.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev))
+        if rc < 0:
+            _glue._fail(rc, "hsr_loss_l1")
+        ctx.grad = None if grad is None else grad.view(shape)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None if ctx.grad is None else ctx.grad * g), None, None, None
+
+
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2):
+        shape = img1.shape
+        a, b = _chw(img1, "img1"), _chw(img2.detach(), "img2")
+        if a.shape != b.shape:
+            raise RuntimeError("hsr_utils.losses: img1 %s and img2 %s differ in shape" % (tuple(shape), tuple(img2.shape)))
+        Cc, H, W = a.shape
+        dev = a.device
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(a) if img1.requires_grad else None
+        sc = _scratch(Cc, H, W, dev)
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_ssim(Cc, H, W, a.data_ptr(), b.data_ptr(), out.data_ptr(), None if grad is None else grad.data_ptr(),
+                                    sc.data_ptr(), sc.numel(), _stream(dev))
+        if rc < 0:
+            _glue._fail(rc, "hsr_loss_ssim")
+        ctx.grad = None if grad is None else grad.view(shape)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None if ctx.grad is None else ctx.grad * g), None
+
+
+class _TreeCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, level_sizes, weights, ignore_index):
+        z = _chw(logits, "logits")
+        K, H, W = z.shape
+        dev = z.device
+        L = len(level_sizes)
+        lab = labels.reshape(-1, H, W)
+        if lab.shape[0] < L:
+            raise RuntimeError("hsr_utils.losses: %d label planes for %d levels" % (lab.shape[0], L))
+        lab = lab[:L].to(device=dev, dtype=torch.int64).contiguous()   # the reference calls .long()
+        sizes = (_ci * L)(*[int(s) for s in level_sizes])
+        w = None if weights is None else (C.c_float * L)(*[float(x) for x in weights])
+        out = torch.empty(L, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(z) if logits.requires_grad else None
+        sc = _scratch(K, H, W, dev)
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_tree_ce(K, H, W, L, sizes, w, z.data_ptr(), lab.data_ptr(), int(ignore_index), out.data_ptr(),
+                                       None if grad is None else grad.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev))
+        if rc < 0:
+            _glue._fail(rc, "hsr_loss_tree_ce")
+        ctx.grad = None if grad is None else grad.view(logits.shape)
+        ctx.mark_non_differentiable(out)
+        if weights is None:
+            return out.sum(), out
+        key = (tuple(float(x) for x in weights), dev)
+        if key not in _weight_cache:
+            _weight_cache[key] = torch.tensor(key[0], dtype=torch.float32, device=dev)
+        return (out * _weight_cache[key]).sum(), out
+
+    @staticmethod
+    def backward(ctx, g_total, g_levels):
+        # the stashed gradient is that of the weighted sum; per-level outputs are reported values (no gradient path)
+        return (None if ctx.grad is None or g_total is None else ctx.grad * g_total), None, None, None, None
+
+
+def l1_loss_v1(x, y):
+    """torch.abs(x - y).mean() (utils/slam_helpers.py:5-6); gradient to x."""
+    return _L1.apply(x, y, None, MEAN)
+
+
+def masked_l1(pred, gt, mask, reduction="sum"):
+    """torch.abs(gt - pred)[mask].sum() / .mean() with a [H,W] or [1,H,W] mask tiled over the channels
+    (scripts/hierslam.py:921-937); gradient to pred.  mask=None selects everything."""
+    return _L1.apply(pred, gt, mask, {"sum": SUM, "mean": MEAN}[reduction])
+
+
+def calc_ssim(img1, img2, window_size=11, size_average=True):
+    """utils/slam_external.py:66-97 for its defaults (11x11 window, mean over the map); gradient to img1."""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("hsr_utils.losses.calc_ssim: only window_size=11, size_average=True (what scripts/hierslam.py uses)")
+    return _SSIM.apply(img1, img2)
+
+
+def mapping_image_loss(im, gt):
+    """0.8 * l1_loss_v1(im, gt) + 0.2 * (1.0 - calc_ssim(im, gt))   (scripts/hierslam.py:939)"""
+    return 0.8 * l1_loss_v1(im, gt) + 0.2 * (1.0 - calc_ssim(im, gt))
+
+
+def tree_cross_entropy(im_semantic, labels, num_semantic, weights=None, ignore_index=-100, return_levels=False):
+    """sum_l w_l * CrossEntropyLoss()(im_semantic[level l channels] as [H*W, n_l], labels[l].view(-1).long())
+    (scripts/hierslam.py:963-974 with transfer_tree_rendered_labelmap, :91-111).  `num_semantic` lists the classes per
+    level; labels is [>= len(num_semantic), H, W].  Gradient to im_semantic."""
+    total, levels = _TreeCE.apply(im_semantic, labels, tuple(num_semantic), None if weights is None else tuple(weights), ignore_index)
+    return (total, levels) if return_levels else total
+
+
+def cross_entropy_planar(logits, labels, ignore_index=-100):
+    """CrossEntropyLoss()(logits.permute(1,2,0).view(-1, C), labels.view(-1).long()) for [C,H,W] logits
+    (flat classes: scripts/hierslam.py:947-954; leaf MLP output: :976-983)."""
+    z = logits[0] if logits.dim() == 4 else logits
+    return tree_cross_entropy(z, labels.reshape(1, z.shape[-2], z.shape[-1]), (z.shape[0],), None, ignore_index)

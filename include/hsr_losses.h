@@ -1,0 +1,62 @@
+/*
+ * hsr_losses.h — C ABI of the fused loss heads on the rendered maps (libhsr_rast.so), SURVEY.md §8(f) rank 2.
+ *
+ * Replaces the torch eager chains of get_loss_semantic_mlp (scripts/hierslam.py:921-1016) that turn the rasterizer's
+ * outputs into scalar losses and — through autograd — into the upstream gradients the rasterizer backward consumes:
+ *   masked depth / colour L1          torch.abs(gt - x)[mask].sum() | .mean()        scripts/hierslam.py:921-937
+ *   l1_loss_v1                        torch.abs(x - y).mean()                        utils/slam_helpers.py:5-6
+ *   calc_ssim                         11x11 Gaussian window, zero padding, mean      utils/slam_external.py:54-97
+ *   multi-level cross-entropy         CrossEntropyLoss per tree level over channel   scripts/hierslam.py:963-974, :993-1003,
+ *                                     ranges of the K logit planes                   transfer_tree_rendered_labelmap :91-111
+ * Every entry point computes the loss value AND d loss / d input in the same call (one read of the maps): the value
+ * goes to a device scalar, the gradient to a caller-owned plane set.  The 1x1-conv leaf MLP (scripts/hierslam.py:1756)
+ * stays a torch Conv2d; its logits go through hsr_loss_tree_ce with one level.
+ *
+ * All pointers are DEVICE pointers (except `level_sizes`, host), planar CHW fp32 as the rasterizer writes them.
+ * Reductions are two-stage with a fixed order: results are reproducible bit for bit.
+ * Errors: return <0 and hsr_last_error() (hsr_rasterizer.h).  No allocation inside the library.
+ */
+#ifndef HSR_LOSSES_H_INCLUDED
+#define HSR_LOSSES_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSR_LOSS_SUM 0  /* torch.abs(..)[mask].sum()   — tracking (scripts/hierslam.py:925, :935, :937) */
+#define HSR_LOSS_MEAN 1 /* torch.abs(..)[mask].mean()  — mapping  (scripts/hierslam.py:927), l1_loss_v1 */
+#define HSR_LOSS_MAX_LEVELS 16
+
+/* bytes of device scratch any entry point below needs for maps of `channels` x H x W */
+size_t hsr_loss_scratch_bytes(int channels, int H, int W);
+
+/* L1 between `pred` and `gt` ([C,H,W]) over the pixels selected by `mask` (uint8 [H,W], shared by the C planes as
+ * torch.tile(mask, (C,1,1)) does; NULL = all pixels).  out_loss: float[1].  out_grad ([C,H,W], may be NULL) receives
+ * d loss / d pred = sign(pred - gt) * (1 or 1/count) on selected pixels, 0 elsewhere.  An empty selection gives
+ * 0 (sum) or NaN (mean), like torch. */
+int hsr_loss_l1(int C, int H, int W, const float* pred, const float* gt, const uint8_t* mask, int reduction, float* out_loss,
+                float* out_grad, char* scratch, size_t scratch_bytes, void* stream);
+
+/* calc_ssim(img1, img2, window_size = 11, size_average = True) (utils/slam_external.py:66-97).  out_ssim: float[1];
+ * out_grad ([C,H,W], may be NULL) receives d ssim / d img1. */
+int hsr_loss_ssim(int C, int H, int W, const float* img1, const float* img2, float* out_ssim, float* out_grad, char* scratch,
+                  size_t scratch_bytes, void* stream);
+
+/* For level l = 0..num_levels-1 with channel range [sum(level_sizes[:l]), +level_sizes[l]) of `logits` ([K,H,W]):
+ *   out_level_loss[l] = CrossEntropyLoss()(logits[range] viewed as [H*W, n_l], labels[l])      (mean over pixels whose
+ * label != ignore_index; torch's default ignore_index is -100).  `labels` is int64 [>= num_levels, H, W] (the reference
+ * calls .long()).  out_grad ([K,H,W], may be NULL) receives d (sum_l level_weight[l] * loss_l) / d logits; channels
+ * outside every level get 0.  `level_sizes` and `level_weight` are HOST arrays of num_levels entries; level_weight == NULL
+ * means all ones.  Labels must lie in [0, level_sizes[l]) or equal ignore_index (torch asserts this; here an out-of-range
+ * label is treated as matching no class). */
+int hsr_loss_tree_ce(int K, int H, int W, int num_levels, const int* level_sizes, const float* level_weight, const float* logits,
+                     const int64_t* labels, int ignore_index, float* out_level_loss, float* out_grad, char* scratch,
+                     size_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSR_LOSSES_H_INCLUDED */

@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "hsr_rasterizer.h")
-HEADERS = [HEADER, os.path.join(ROOT, "include", "hsr_frame_prep.h")]
+HEADERS = [HEADER, os.path.join(ROOT, "include", "hsr_frame_prep.h"), os.path.join(ROOT, "include", "hsr_losses.h")]
 
 
 def _prototypes():
@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
     assert {"hsr_forward", "hsr_forward_semantic", "hsr_backward", "hsr_backward_semantic", "hsr_mark_visible",
             "hsr_required_geometry_bytes", "hsr_required_image_bytes", "hsr_required_binning_bytes", "hsr_last_error",
             "hsr_version", "hsr_get_state_layout", "hsr_profile_enable", "hsr_profile_read", "hsr_stage_name",
-            "hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes"} <= set(protos)
+            "hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes",
+            "hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_scratch_bytes"} <= set(protos)
     lib = C.CDLL(_C._LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), "libhsr_rast.so does not export %s" % name
@@ -46,6 +47,10 @@ def test_ctypes_signatures_match_header():
     from hsr_utils import slam_helpers
     for name in ("hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes"):
         fn = getattr(slam_helpers._lib, name)
+        assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
+    from hsr_utils import losses
+    for name in ("hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_scratch_bytes"):
+        fn = getattr(losses._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
 
 
@@ -82,6 +87,11 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"log_scales must be" in lib.hsr_last_error()
     rc = lib.hsr_frame_prep_backward(0, 1, 0, 0, *([null] * 6), 1, 5, *([null] * 14), 0, null)
     assert rc == -1 and b"time_idx" in lib.hsr_last_error()
+    from hsr_utils import losses  # sets the argtypes of the loss entry points
+    assert losses._lib.hsr_loss_scratch_bytes(3, 680, 1200) >= 3 * 3 * 680 * 1200 * 4
+    assert lib.hsr_loss_l1(0, 8, 8, null, null, null, 0, null, null, null, 0, null) == -1 and b"loss_l1" in lib.hsr_last_error()
+    assert lib.hsr_loss_ssim(3, 0, 8, null, null, null, null, null, 0, null) == -1
+    assert lib.hsr_loss_tree_ce(4, 8, 8, 1, None, None, null, null, -100, null, null, null, 0, null) == -1
 
 
 def test_no_cpu_fallback_and_reference_error_messages():
