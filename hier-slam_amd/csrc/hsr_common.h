@@ -116,7 +116,7 @@ struct RenderFwdArgs {
     int debug_flags;  // ablation switches for tools/ablate.sh (wide kernel: 1 no MFMA, 2 no row gather, 4 no blend loop); 0 in production
 };
 int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream);
-int hsr_launch_render_forward_mfma(const RenderFwdArgs& a, hipStream_t stream);  // returns #semantic channels produced
+bool hsr_launch_render_forward_pair(const RenderFwdArgs& a, hipStream_t stream);  // non-semantic / K <= 27, pair-pipelined MFMA
 bool hsr_launch_render_forward_wide(const RenderFwdArgs& a, hipStream_t stream);  // semantic, 29 <= K <= 124; false otherwise
 
 struct RenderBwdArgs {

@@ -218,17 +218,12 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
     const dim3 grid(tiles), block(256);
-    // default: the all-VALU kernels below.  HSR_FWD_IMPL=mfma selects the matrix-core accumulation
-    // (hsr_render_fwd_mfma.hip: base outputs + the first 27 semantic channels, VALU chunks for the rest): correct and
-    // 40 % fewer VALU instructions, but 0.31 vs 0.22 ms at the headline workload (168 registers -> 3 waves/SIMD and an
-    // exposed LDS round trip per pair; the forward is bound by per-wave latency, not by VALU issue).
-    static const bool use_mfma = getenv("HSR_FWD_IMPL") && !strcmp(getenv("HSR_FWD_IMPL"), "mfma");
-    if (use_mfma) {
-        const int done = hsr_launch_render_forward_mfma(a, stream);
-        if (a.semantic)
-            for (int c0 = done; c0 < a.K; c0 += 32) render_fwd_kernel<32, false, false, false><<<grid, block, 0, stream>>>(a, c0);
-        return HSR_OK;
-    }
+    // default for K <= 27: the per-lane kernels below.  HSR_FWD_IMPL=mfma selects the pair-pipelined matrix-core kernel
+    // (hsr_render_fwd_pair.hip): parity-tested, but 0.27 vs 0.22 ms at the headline workload — the ~25 VALU instructions
+    // that evaluate alpha per list entry dominate, the matrix cores only take the 15 packed FMAs behind them, and every
+    // list entry (not only contributing ones) has to go through the pair.
+    static const bool use_pair = getenv("HSR_FWD_IMPL") && !strcmp(getenv("HSR_FWD_IMPL"), "mfma");
+    if (use_pair && hsr_launch_render_forward_pair(a, stream)) return HSR_OK;
     if (!a.semantic) {
         render_fwd_kernel<0, true, true, false><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;
