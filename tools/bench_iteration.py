@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""One mapping iteration of the SLAM loop around the rasterizer (scripts/hierslam.py:870-1016, :2016-2037 without the
+optimizer): world->camera preparation, semantic render, mapping losses, backward to every Gaussian parameter and the pose.
+Times (a) the fused preparation + rasterizer + fused loss heads of this repo and (b) the same rasterizer with the
+reference's torch eager chains either side of it.  One JSON line.
+
+    python tools/bench_iteration.py [--P 500000] [--iters 20]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hier-slam_amd"))
+
+
+def measure(P=500000, W=1200, H=680, iters=20):
+    from diff_gaussian_rasterization import GaussianRasterizer_semantic
+    from hsr_utils import slam_helpers as SH, losses as L, setup_camera, make_scene
+    from hsr_utils.camera import replica_intrinsics
+    sizes = [2, 4, 6, 6, 8]
+    K = sum(sizes)
+    kmat = replica_intrinsics(W, H)
+    cam = setup_camera(W, H, kmat, np.eye(4), device="cuda")
+    sc = make_scene(P, W, H, K, kmat, seed=0)
+    g = torch.Generator().manual_seed(0)
+    params = {"means3D": sc["means3D"], "unnorm_rotations": sc["rotations"], "logit_opacities": torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)),
+              "log_scales": sc["scales"][:, :1].log(), "rgb_colors": sc["colors_precomp"], "semantic": sc["semantics_precomp"]}
+    params = {k: v.clone().cuda().requires_grad_(True) for k, v in params.items()}
+    rots = torch.zeros(1, 4, 4); rots[0, 0] = 1.0
+    params["cam_unnorm_rots"] = rots.cuda().requires_grad_(True)
+    params["cam_trans"] = torch.zeros(1, 3, 4).cuda().requires_grad_(True)
+    gt_im, gt_d = torch.rand(3, H, W, generator=g).cuda(), (torch.rand(1, H, W, generator=g) * 5 + 0.5).cuda()
+    lab = torch.stack([torch.randint(0, n, (H, W), generator=g) for n in sizes]).cuda()
+    w1 = torch.tensor([np.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
+    w1 = (w1 / w1.sum()).unsqueeze(1)
+    win = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0).expand(3, 1, 11, 11).contiguous().cuda()
+
+    def eager_prep(p, tidx):
+        q = F.normalize(p['cam_unnorm_rots'][..., tidx])
+        nq = q / torch.sqrt((q * q).sum(dim=1))[:, None]
+        r, x, y, z = nq[:, 0], nq[:, 1], nq[:, 2], nq[:, 3]
+        rot = torch.zeros((1, 3, 3), device="cuda")
+        rot[:, 0, 0] = 1 - 2 * (y * y + z * z); rot[:, 0, 1] = 2 * (x * y - r * z); rot[:, 0, 2] = 2 * (x * z + r * y)
+        rot[:, 1, 0] = 2 * (x * y + r * z); rot[:, 1, 1] = 1 - 2 * (x * x + z * z); rot[:, 1, 2] = 2 * (y * z - r * x)
+        rot[:, 2, 0] = 2 * (x * z - r * y); rot[:, 2, 1] = 2 * (y * z + r * x); rot[:, 2, 2] = 1 - 2 * (x * x + y * y)
+        rel = torch.eye(4, device="cuda"); rel[:3, :3] = rot[0]; rel[:3, 3] = p['cam_trans'][0, :, tidx]
+        pts4 = torch.cat((p['means3D'], torch.ones(P, 1, device="cuda")), dim=1)
+        return {'means3D': (rel @ pts4.T).T[:, :3], 'colors_precomp': p['rgb_colors'], 'rotations': F.normalize(p['unnorm_rotations']),
+                'opacities': torch.sigmoid(p['logit_opacities']), 'scales': torch.exp(torch.tile(p['log_scales'], (1, 3))),
+                'semantics_precomp': p['semantic'], 'means2D': torch.zeros_like(p['means3D'], requires_grad=True) + 0}
+
+    def eager_ssim(a, b):
+        mu1, mu2 = F.conv2d(a, win, padding=5, groups=3), F.conv2d(b, win, padding=5, groups=3)
+        s1 = F.conv2d(a * a, win, padding=5, groups=3) - mu1.pow(2)
+        s2 = F.conv2d(b * b, win, padding=5, groups=3) - mu2.pow(2)
+        s12 = F.conv2d(a * b, win, padding=5, groups=3) - mu1 * mu2
+        return (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1.pow(2) + mu2.pow(2) + 1e-4) * (s1 + s2 + 9e-4))).mean()
+
+    def iteration(fused):
+        rv = SH.transformed_params2rendervar_semantic(params, SH.transform_to_frame(params, 1, True, False)) if fused else eager_prep(params, 1)
+        rv['means2D'].retain_grad()
+        im, radius, sem, depth, med, opac = GaussianRasterizer_semantic(raster_settings=cam)(**rv)
+        mask = ((gt_d > 0) & ~torch.isnan(depth)).detach()
+        if fused:
+            loss = 0.5 * L.mapping_image_loss(im, gt_im) + L.masked_l1(depth, gt_d, mask, "mean") + 0.1 * L.tree_cross_entropy(sem, lab, sizes)
+        else:
+            ce, b = 0.0, 0
+            celoss = torch.nn.CrossEntropyLoss()
+            for i, n in enumerate(sizes):
+                lvl = sem[b:b + n].permute(1, 2, 0)
+                ce = ce + celoss(lvl.reshape(-1, n), lab[i].view(-1).long())
+                b += n
+            loss = 0.5 * (0.8 * torch.abs(im - gt_im).mean() + 0.2 * (1.0 - eager_ssim(im, gt_im))) + torch.abs(gt_d - depth)[mask].mean() + 0.1 * ce
+        loss.backward()
+        return loss
+
+    def timeit(fused):
+        for _ in range(3):
+            iteration(fused)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            for v in params.values():
+                v.grad = None
+            iteration(fused)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+    lf, le = float(iteration(True).detach()), float(iteration(False).detach())
+    return {"workload": "mapping iteration without optimizer: prep + semantic render + mapping losses + backward, %dx%d, P=%d, K=%d" % (W, H, P, K),
+            "fused_ms": timeit(True), "eager_around_same_rasterizer_ms": timeit(False), "loss_fused": lf, "loss_eager": le}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--P", type=int, default=500000)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    print(json.dumps(measure(a.P, iters=a.iters)))
