@@ -238,19 +238,32 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     hsr_carve_bin(bptr, R, &b);
 
     const int end_bit = 32 + (int)higher_msb((uint32_t)T);  // rasterizer_impl.cu:304-312
-    // emit into the buffer pair from which the sort's ping-pong passes end in (keys, vals)
-    const bool emit_sorted = hsr_sort_emit_into_sorted_buffers(end_bit);
-    uint64_t* emit_k = emit_sorted ? b.keys : b.keys_unsorted;
-    uint32_t* emit_v = emit_sorted ? b.vals : b.vals_unsorted;
-    {
+    // Default: count per tile, emit every instance straight into its tile's segment, then order each segment by
+    // (depth, index) in LDS (hsr_launch_bin_tiles).  HSR_SORT_IMPL=radix, more than 8192 tiles or a tiny R take the
+    // emission-order + stable tile-bit radix passes instead; both give the same sorted keys, values and ranges.
+    static const bool force_radix = getenv("HSR_SORT_IMPL") && !strcmp(getenv("HSR_SORT_IMPL"), "radix");
+    bool binned = false;
+    if (!force_radix) {
         StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
-        BinState be = b;
-        be.keys_unsorted = emit_k;
-        be.vals_unsorted = emit_v;
-        hsr_launch_duplicate(P, radii, tiles_x, tiles_y, g, be, im.ranges, stream);
+        binned = hsr_launch_bin_tiles(P, R, radii, tiles_x, tiles_y, g, b, im.ranges, stream);
     }
-    HSR_LAUNCH_CHECK(in.debug, stream);
-    {
+    if (binned) {
+        HSR_LAUNCH_CHECK(in.debug, stream);
+        StageTimer tm(HSR_STAGE_FWD_SORT, stream);
+        hsr_launch_tile_sort(b, T, P, im.ranges, stream);
+    } else {
+        // emit into the buffer pair from which the sort's ping-pong passes end in (keys, vals)
+        const bool emit_sorted = hsr_sort_emit_into_sorted_buffers(end_bit);
+        uint64_t* emit_k = emit_sorted ? b.keys : b.keys_unsorted;
+        uint32_t* emit_v = emit_sorted ? b.vals : b.vals_unsorted;
+        {
+            StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
+            BinState be = b;
+            be.keys_unsorted = emit_k;
+            be.vals_unsorted = emit_v;
+            hsr_launch_duplicate(P, radii, tiles_x, tiles_y, g, be, im.ranges, stream);
+        }
+        HSR_LAUNCH_CHECK(in.debug, stream);
         // tile-bit radix passes -> tile ranges -> per-tile depth sort (ranges are a by-product of the sort)
         StageTimer tm(HSR_STAGE_FWD_SORT, stream);
         if ((rc = hsr_launch_sort_pairs(b, R, end_bit, T, im.ranges, stream)) != HSR_OK) return rc;

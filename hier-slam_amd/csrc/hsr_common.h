@@ -91,6 +91,9 @@ int hsr_launch_scan_block_sums(int P, GeomState& g, hipStream_t stream);
 int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, uint2* ranges,
                          hipStream_t stream);  // also zeroes ranges[0, tiles)
 int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, int T, uint2* ranges, hipStream_t stream);  // also fills ranges
+bool hsr_launch_bin_tiles(int P, int R, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, uint2* ranges,
+                          hipStream_t stream);  // direct binning into (b.keys, b.vals) + ranges; false = not applicable
+int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream);  // per-tile (depth, index) sort
 int hsr_sort_tile_passes(int end_bit);
 bool hsr_sort_emit_into_sorted_buffers(int end_bit);
 int hsr_launch_tile_ranges(int R, int T, const uint64_t* keys, uint2* ranges, hipStream_t stream);

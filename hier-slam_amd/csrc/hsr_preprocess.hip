@@ -307,6 +307,146 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t*
     if (idx == L - 1) ranges[cur].y = L;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Direct tile binning (T <= BIN_MAX_TILES): instead of emitting the instances in Gaussian order and radix-sorting them
+// on the tile bits (2 passes of histogram / scan / scatter over all R pairs at 1200x680), count per tile first and emit
+// every instance straight into its tile's segment:
+//   bin_hist   : workgroup b owns a contiguous range of Gaussians, counts their tiles in LDS (ds_add), writes row b of
+//                table[nblk][T]; also finishes the per-Gaussian inclusive scan (point_offsets), which no longer feeds
+//                the emission but is part of the state the reference keeps (rasterizer_impl.cu:281);
+//   bin_scan   : thread = tile: exclusive prefix over the nblk rows in place, tile totals;
+//   bin_offsets: one workgroup: exclusive scan of the tile totals = tile segment starts = the reference's tile ranges
+//                (identifyTileRanges, rasterizer_impl.cu:116-138; untouched tiles keep {0,0} as after its memset, :314);
+//   bin_emit   : same ownership as bin_hist; LDS cursors (segment start + row prefix), ds_add_rtn gives each instance
+//                its slot (it stores the 8-byte sort composite (depth bits, index) there; the tile is implied by the
+//                segment).  The order INSIDE a tile segment is whatever the LDS atomics produce — irrelevant, because
+//                tile_sort_kernel then orders each segment by the unique composite (depth bits, Gaussian index), which
+//                is exactly the order a stable sort of the emission order on (tile, depth) gives.
+// Bit-identical sorted keys / values / ranges, 4 small launches instead of 8, and the 12 B x R unsorted copy is gone.
+constexpr int BIN_MAX_TILES = 8192;   // LDS: one u32 counter per tile
+
+constexpr int BIN_THREADS = 1024;     // 16 waves per workgroup: each workgroup touches all T counters twice (zero / read
+                                      // out), so few large workgroups with many waves beat many small ones
+
+__global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_block, const int* __restrict__ radii, int tiles_x,
+                                                               int tiles_y, GeomState g, uint32_t* __restrict__ table)
+{
+    extern __shared__ uint32_t s_cnt[];   // [T]
+    __shared__ uint32_t s_wsum[BIN_THREADS / 64];
+    const int T = tiles_x * tiles_y;
+    for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cnt[i] = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g0 = blockIdx.x * per_block;   // per_block is a multiple of 1024: chunks coincide with 4 preprocess blocks
+    for (int c = 0; c < per_block && g0 + c < P; c += BIN_THREADS) {
+        const int idx = g0 + c + threadIdx.x;
+        const uint32_t touched = idx < P ? g.tiles_touched[idx] : 0u;
+        // inclusive scan inside the wave, then the sums of the earlier waves of the same 256-Gaussian preprocess block
+        uint32_t inc = touched;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        __syncthreads();
+        if (lane == 63) s_wsum[w] = inc;
+        __syncthreads();
+        uint32_t off = g.block_sums[idx < P ? idx >> 8 : 0];
+        for (int k = w & ~3; k < w; k++) off += s_wsum[k];
+        if (idx < P) {
+            g.point_offsets[idx] = off + inc;
+            const int radius = radii[idx];
+            if (radius > 0) {
+                const float2 xy = g.means2D[idx];
+                uint32_t x0, y0, x1, y1;
+                tile_rect(xy.x, xy.y, radius, tiles_x, tiles_y, x0, y0, x1, y1);
+                for (uint32_t y = y0; y < y1; y++)
+                    for (uint32_t x = x0; x < x1; x++) atomicAdd(&s_cnt[y * (uint32_t)tiles_x + x], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T; i += BIN_THREADS) row[i] = s_cnt[i];
+}
+
+// workgroup = 64 tiles x 16 row groups: every thread sums its group of rows for one tile (a wave reads 256 contiguous
+// bytes per row), the 16 group sums are scanned through LDS, then the thread writes the exclusive prefixes of its rows
+__global__ void __launch_bounds__(1024) bin_scan_kernel(int T, int nblk, uint32_t* __restrict__ table, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_sum[16][65];
+    const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tl;
+    const int rows = (nblk + 15) / 16;
+    const int b0 = grp * rows, b1 = min(nblk, b0 + rows);
+    uint32_t sum = 0;
+    if (i < T)
+        for (int b = b0; b < b1; b++) sum += table[(size_t)b * T + i];
+    s_sum[grp][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t v = s_sum[k][tl];
+        run += k < grp ? v : 0u;
+        tot += v;
+    }
+    if (i >= T) return;
+    if (grp == 0) totals[i] = tot;
+    for (int b = b0; b < b1; b++) {
+        const uint32_t c = table[(size_t)b * T + i];
+        table[(size_t)b * T + i] = run;
+        run += c;
+    }
+}
+
+__global__ void __launch_bounds__(1024) bin_offsets_kernel(int T, const uint32_t* __restrict__ totals, uint32_t* __restrict__ base,
+                                                           uint2* __restrict__ ranges)
+{
+    __shared__ uint32_t smem[1024 / 64 + 1];
+    const int per = (T + 1023) / 1024;
+    const int beg = threadIdx.x * per;
+    uint32_t local = 0;
+    for (int i = 0; i < per; i++)
+        if (beg + i < T) local += totals[beg + i];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan<1024>(local, smem, total);
+    for (int i = 0; i < per; i++) {
+        const int j = beg + i;
+        if (j < T) {
+            const uint32_t c = totals[j];
+            base[j] = run;
+            ranges[j] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);
+            run += c;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) bin_emit_kernel(int P, int per_block, const int* __restrict__ radii, int tiles_x, int tiles_y,
+                                                       GeomState g, const uint32_t* __restrict__ table, const uint32_t* __restrict__ base,
+                                                       uint64_t* __restrict__ comp)
+{
+    extern __shared__ uint32_t s_cur[];   // [T]
+    const int T = tiles_x * tiles_y;
+    const uint32_t* row = table + (size_t)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cur[i] = base[i] + row[i];
+    __syncthreads();
+    const int g0 = blockIdx.x * per_block;
+    const int g1 = min(P, g0 + per_block);
+    for (int idx = g0 + threadIdx.x; idx < g1; idx += BIN_THREADS) {
+        const int radius = radii[idx];
+        if (radius <= 0) continue;
+        const float2 xy = g.means2D[idx];
+        uint32_t x0, y0, x1, y1;
+        tile_rect(xy.x, xy.y, radius, tiles_x, tiles_y, x0, y0, x1, y1);
+        // the tile is implied by the segment: one 8-byte store of the sort composite (depth bits, index) per instance;
+        // tile_sort_kernel turns it into the reference's (tile | depth) key and the index value
+        const uint64_t c = ((uint64_t)__float_as_uint(g.depths[idx]) << 32) | (uint64_t)(uint32_t)idx;
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) comp[atomicAdd(&s_cur[y * (uint32_t)tiles_x + x], 1u)] = c;
+    }
+}
+
 }  // namespace
 
 int hsr_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
@@ -335,6 +475,33 @@ int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, Geom
 {
     duplicate_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, radii, tiles_x, tiles_y, g, b.keys_unsorted, b.vals_unsorted, ranges);
     return HSR_OK;
+}
+
+// Direct tile binning (see bin_hist_kernel).  Scratch = the keys_unsorted array, which this path does not otherwise use
+// (8 bytes x R); returns false — caller takes the radix path — when there are too many tiles for LDS counters or R is too
+// small to hold the count table of even a few workgroups.
+bool hsr_launch_bin_tiles(int P, int R, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, uint2* ranges,
+                          hipStream_t stream)
+{
+    const int T = tiles_x * tiles_y;
+    if (T > BIN_MAX_TILES || P <= 0 || R <= 0) return false;
+    const size_t cap_words = (size_t)R * 2;                       // u32 words available in keys_unsorted
+    if (cap_words < (size_t)T * (2 + 8)) return false;
+    int nblk = (P + 2047) / 2048;
+    const size_t max_blk = (cap_words - 2 * (size_t)T) / (size_t)T;
+    if ((size_t)nblk > max_blk) nblk = (int)max_blk;
+    if (nblk > 2048) nblk = 2048;
+    int per_block = ((P + nblk - 1) / nblk + BIN_THREADS - 1) & ~(BIN_THREADS - 1);   // multiple of 1024
+    nblk = (P + per_block - 1) / per_block;
+    uint32_t* table = reinterpret_cast<uint32_t*>(b.keys_unsorted);
+    uint32_t* totals = table + (size_t)nblk * T;
+    uint32_t* base = totals + T;
+    const size_t lds = (size_t)T * sizeof(uint32_t);
+    bin_hist_kernel<<<nblk, BIN_THREADS, lds, stream>>>(P, per_block, radii, tiles_x, tiles_y, g, table);
+    bin_scan_kernel<<<(T + 63) / 64, 1024, 0, stream>>>(T, nblk, table, totals);
+    bin_offsets_kernel<<<1, 1024, 0, stream>>>(T, totals, base, ranges);
+    bin_emit_kernel<<<nblk, BIN_THREADS, lds, stream>>>(P, per_block, radii, tiles_x, tiles_y, g, table, base, b.keys);
+    return true;
 }
 
 int hsr_launch_tile_ranges_only(int R, const uint64_t* keys, uint2* ranges, hipStream_t stream)

@@ -164,22 +164,27 @@ uint32_t hsr_sort_hist_entries(int R)
 // (depth, index) pairs are unique inside a tile, sorting the composite key (depth << 32) | index with ANY
 // network gives exactly that order.  One workgroup per tile:
 //   n <= TS_MAX : bitonic network on composite keys in LDS (padding = +inf keys);
-//   n  > TS_MAX : block-local stable LSD radix on the 32 depth bits, ping-ponging inside the tile's own segment
-//                 of the two global buffer pairs (segments of different tiles are disjoint).
+//   n  > TS_MAX : block-local stable LSD radix on the 32 depth bits — preceded by the Gaussian-index bytes when the
+//                 segment does not arrive in emission order (direct binning) — ping-ponging inside the tile's own
+//                 segment of the two global buffer pairs (segments of different tiles are disjoint).
 constexpr int TS_MAX = 2048;
 
 __device__ __forceinline__ void ts_block_radix(uint64_t* ka, uint32_t* va, uint64_t* kb, uint32_t* vb, int r0, int n,
-                                               uint32_t* hist /*[256]*/, uint32_t (*wcnt)[256])
+                                               uint32_t* hist /*[256]*/, uint32_t (*wcnt)[256], int gid_passes)
 {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 8 * pass;
+    // LSD over the composite (depth bits, Gaussian index): index bytes first, then the four depth bytes
+    const int npass = gid_passes + 4;
+    for (int pass = 0; pass < npass; pass++) {
+        const bool on_gid = pass < gid_passes;
+        const int shift = 8 * (on_gid ? pass : pass - gid_passes);
         hist[t] = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) wcnt[i][t] = 0;
         __syncthreads();
-        for (int i = t; i < n; i += 256) atomicAdd(&hist[(uint32_t)(ka[r0 + i] >> shift) & 255u], 1u);
+        for (int i = t; i < n; i += 256)
+            atomicAdd(&hist[((on_gid ? va[r0 + i] : (uint32_t)ka[r0 + i]) >> shift) & 255u], 1u);
         __syncthreads();
         // exclusive scan of the 256 counts (thread t <-> digit t)
         {
@@ -204,7 +209,7 @@ __device__ __forceinline__ void ts_block_radix(uint64_t* ka, uint32_t* va, uint6
             const bool valid = i < n;
             const uint64_t k = valid ? ka[r0 + i] : 0ull;
             const uint32_t v = valid ? va[r0 + i] : 0u;
-            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const uint32_t d = ((on_gid ? v : (uint32_t)k) >> shift) & 255u;
             uint64_t m = __ballot(valid);
 #pragma unroll
             for (int b = 0; b < 8; b++) {
@@ -232,28 +237,48 @@ __device__ __forceinline__ void ts_block_radix(uint64_t* ka, uint32_t* va, uint6
         uint32_t* tv = va; va = vb; vb = tv;
         __threadfence_block();
     }
+    if (npass & 1) {  // an odd number of passes ends in the alternate pair: bring the segment home
+        __syncthreads();
+        for (int i = t; i < n; i += 256) {
+            kb[r0 + i] = ka[r0 + i];
+            vb[r0 + i] = va[r0 + i];
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
                                                         uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
-                                                        uint32_t* __restrict__ vals_alt)
+                                                        uint32_t* __restrict__ vals_alt, int gid_passes, int composite_in)
 {
     __shared__ uint64_t comp[TS_MAX];
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wcnt[4][256];
     const uint2 rg = ranges[blockIdx.x];
     const int r0 = (int)rg.x, n = (int)(rg.y - rg.x);
-    if (n <= 1) return;
     const int t = threadIdx.x;
+    // composite_in (direct binning): keys[] holds (depth bits << 32) | index per instance, the tile is the workgroup's
+    const uint64_t my_tile_hi = (uint64_t)blockIdx.x << 32;
+    if (n <= 0) return;
+    if (n == 1 || n > TS_MAX) {
+        if (composite_in) {
+            for (int i = t; i < n; i += 256) {
+                const uint64_t c = keys[r0 + i];
+                keys[r0 + i] = my_tile_hi | (c >> 32);
+                vals[r0 + i] = (uint32_t)c;
+            }
+            __syncthreads();
+        }
+        if (n == 1) return;
+    }
     if (n > TS_MAX) {
-        ts_block_radix(keys, vals, keys_alt, vals_alt, r0, n, hist, wcnt);  // 4 passes: ends in (keys, vals)
+        ts_block_radix(keys, vals, keys_alt, vals_alt, r0, n, hist, wcnt, gid_passes);  // ends in (keys, vals)
         return;
     }
     int N = 64;
     while (N < n) N <<= 1;
-    const uint64_t tile_hi = keys[r0] & 0xFFFFFFFF00000000ull;
+    const uint64_t tile_hi = composite_in ? my_tile_hi : (keys[r0] & 0xFFFFFFFF00000000ull);
     for (int i = t; i < N; i += 256)
-        comp[i] = i < n ? (((keys[r0 + i] & 0xFFFFFFFFull) << 32) | (uint64_t)vals[r0 + i]) : ~0ull;
+        comp[i] = i < n ? (composite_in ? keys[r0 + i] : (((keys[r0 + i] & 0xFFFFFFFFull) << 32) | (uint64_t)vals[r0 + i])) : ~0ull;
     __syncthreads();
     for (int k = 2; k <= N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -315,6 +340,16 @@ int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, int T, uint2* ranges,
     }
     // (b.keys, b.vals) now hold the instances grouped by tile, in emission order inside each tile
     hsr_launch_tile_ranges_only(R, b.keys, ranges, stream);
-    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted);
+    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, 0, 0);
+    return HSR_OK;
+}
+
+// Per-tile sort alone, for segments in ARBITRARY order holding the 8-byte composites written by direct tile binning
+// (hsr_launch_bin_tiles): tiles above TS_MAX entries radix-sort the Gaussian-index bytes before the depth bytes.
+int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream)
+{
+    int bits = 0;
+    while (bits < 32 && (1ull << bits) < (unsigned long long)(P > 1 ? P : 1)) bits++;
+    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 1);
     return HSR_OK;
 }
