@@ -161,10 +161,23 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    prof = None
+    # Stage timers cost two event records per stage and call, and eight timed stages per step slow the launch sequence
+    # down by ~8 %.  So: (1) an UNTIMED instrumented pre-pass gives the full stage table and names the dominant stage;
+    # (2) during the timed region only that stage is bracketed by HIP events (on the launch stream, inside the library).
+    prof = prof_all = None
+    dom_stage = -1
     if not args.no_profile:
         _C._lib.hsr_profile_read(None, 1)
+        _C._lib.hsr_profile_select(0xFFFFFFFF)
         _C._lib.hsr_profile_enable(1)
+        n_pre = max(3, min(10, args.warmup))
+        for _ in range(n_pre):
+            step()
+        sync()
+        prof_all = _Profile()
+        _C._lib.hsr_profile_read(C.byref(prof_all), 1)
+        dom_stage = max(range(9), key=lambda i: prof_all.ms[i])
+        _C._lib.hsr_profile_select(1 << dom_stage)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -174,6 +187,7 @@ def main():
         prof = _Profile()
         _C._lib.hsr_profile_enable(0)
         _C._lib.hsr_profile_read(C.byref(prof), 1)
+        _C._lib.hsr_profile_select(0xFFFFFFFF)
     elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -201,9 +215,10 @@ def main():
             for i in range(9):
                 nm = _C._lib.hsr_stage_name(i)
                 nm = nm.decode() if isinstance(nm, bytes) else C.cast(nm, C.c_char_p).value.decode()
-                if prof.calls[i]:
-                    stages[nm] = {"ms": prof.ms[i] / prof.calls[i], "alg_bytes": alg[nm],
-                                  "GBps": alg[nm] / (prof.ms[i] / prof.calls[i] * 1e-3) / 1e9}
+                # per STEP (a stage can be several timed sections per step); dominant stage: from the timed region
+                src, nst = (prof, args.steps) if (i == dom_stage and prof.calls[i]) else (prof_all, n_pre)
+                if src.calls[i]:
+                    stages[nm] = {"ms": src.ms[i] / nst, "alg_bytes": alg[nm], "GBps": alg[nm] / (src.ms[i] / nst * 1e-3) / 1e9}
             dom = max(stages, key=lambda n: stages[n]["ms"])
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": stages[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
@@ -219,6 +234,9 @@ def main():
             except Exception:
                 pass
             out["stages_ms"] = {n: round(v["ms"], 4) for n, v in stages.items()}
+            out["stages_note"] = ("HIP events inside the library on the launch stream; the roofline kernel (%s) is timed during the "
+                                  "timed region, the other stages in an untimed instrumented pre-pass (timing all eight stages "
+                                  "costs ~8 %% of the step)" % dom)
             tot_alg = sum(alg.values())
             out["whole_render"] = {"alg_bytes": tot_alg, "GBps": tot_alg / (ms_per_step * 1e-3) / 1e9,
                                    "frac_of_hbm_peak": tot_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,

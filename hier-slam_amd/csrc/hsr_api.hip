@@ -87,6 +87,7 @@ struct StageEvents {
     hipEvent_t start, stop;
 };
 bool g_prof_on = false;
+unsigned g_prof_mask = ~0u;
 std::mutex g_prof_mu;
 std::vector<StageEvents> g_prof_pending;
 std::vector<hipEvent_t> g_prof_free;
@@ -109,7 +110,7 @@ struct StageTimer {
     hipEvent_t start = nullptr, stop = nullptr;
     StageTimer(int st, hipStream_t s) : stage(st), stream(s)
     {
-        if (!g_prof_on) return;
+        if (!g_prof_on || !((g_prof_mask >> st) & 1u)) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         start = prof_get_event();
         stop = prof_get_event();
@@ -124,11 +125,20 @@ struct StageTimer {
     }
 };
 
-int read_counter(const uint32_t* dev, uint32_t* host_out, hipStream_t stream)
+// num_rendered read-back in two steps: the copy is enqueued right behind the scan, the host waits only after it has
+// enqueued the work that does not depend on the value (an event, not a stream sync, so that work keeps the GPU busy)
+thread_local hipEvent_t g_counter_event = nullptr;
+int read_counter_begin(const uint32_t* dev, hipStream_t stream)
 {
     if (!g_pinned) HSR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_pinned), 64, hipHostMallocDefault));
+    if (!g_counter_event) HSR_HIP_CHECK(hipEventCreateWithFlags(&g_counter_event, hipEventDisableTiming));
     HSR_HIP_CHECK(hipMemcpyAsync(g_pinned, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HSR_HIP_CHECK(hipStreamSynchronize(stream));
+    HSR_HIP_CHECK(hipEventRecord(g_counter_event, stream));
+    return HSR_OK;
+}
+int read_counter_end(uint32_t* host_out)
+{
+    HSR_HIP_CHECK(hipEventSynchronize(g_counter_event));
     *host_out = g_pinned[0];
     return HSR_OK;
 }
@@ -224,8 +234,25 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     }
     HSR_LAUNCH_CHECK(in.debug, stream);
 
+    if ((rc = read_counter_begin(g.counters, stream)) != HSR_OK) return rc;
+
+    const int end_bit = 32 + (int)higher_msb((uint32_t)T);  // rasterizer_impl.cu:304-312
+    // Default: count per tile, emit every instance straight into its tile's segment, then order each segment by
+    // (depth, index) in LDS.  HSR_SORT_IMPL=radix or more than 8192 tiles take the emission-order + stable tile-bit
+    // radix passes instead; both give the same sorted keys, values and ranges.  The count phase needs neither
+    // num_rendered nor the binning buffer, so it is enqueued BEFORE the host waits for num_rendered: the GPU works
+    // through it while the host wakes up (the reference idles the stream at this point, rasterizer_impl.cu:285).
+    static const bool force_radix = getenv("HSR_SORT_IMPL") && !strcmp(getenv("HSR_SORT_IMPL"), "radix");
+    HsrBinPlan plan{0, 0};
+    uint32_t* bin_scratch = reinterpret_cast<uint32_t*>(im.final_T);   // free until the render kernel writes it
+    const bool binned = !force_radix && hsr_bin_plan(P, T, (size_t)W * H, &plan);
+    if (binned) {
+        StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
+        hsr_launch_bin_count(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, stream);
+    }
+
     uint32_t R32 = 0;
-    if ((rc = read_counter(g.counters, &R32, stream)) != HSR_OK) return rc;
+    if ((rc = read_counter_end(&R32)) != HSR_OK) return rc;
     if (R32 > 0x7fffffffu) {
         hsr_set_error("num_rendered %u overflows int", R32);
         return HSR_ERR_INVALID_ARGUMENT;
@@ -237,20 +264,14 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     BinState b;
     hsr_carve_bin(bptr, R, &b);
 
-    const int end_bit = 32 + (int)higher_msb((uint32_t)T);  // rasterizer_impl.cu:304-312
-    // Default: count per tile, emit every instance straight into its tile's segment, then order each segment by
-    // (depth, index) in LDS (hsr_launch_bin_tiles).  HSR_SORT_IMPL=radix, more than 8192 tiles or a tiny R take the
-    // emission-order + stable tile-bit radix passes instead; both give the same sorted keys, values and ranges.
-    static const bool force_radix = getenv("HSR_SORT_IMPL") && !strcmp(getenv("HSR_SORT_IMPL"), "radix");
-    bool binned = false;
-    if (!force_radix) {
+    if (binned && R > 0) {
         StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
-        binned = hsr_launch_bin_tiles(P, R, radii, tiles_x, tiles_y, g, b, im.ranges, stream);
+        hsr_launch_bin_emit(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, b.keys, stream);
     }
     if (binned) {
         HSR_LAUNCH_CHECK(in.debug, stream);
         StageTimer tm(HSR_STAGE_FWD_SORT, stream);
-        hsr_launch_tile_sort(b, T, P, im.ranges, stream);
+        if (R > 0) hsr_launch_tile_sort(b, T, P, im.ranges, stream);
     } else {
         // emit into the buffer pair from which the sort's ping-pong passes end in (keys, vals)
         const bool emit_sorted = hsr_sort_emit_into_sorted_buffers(end_bit);
@@ -524,6 +545,13 @@ int hsr_set_backward_mode(int mode)
         return HSR_ERR_INVALID_ARGUMENT;
     }
     g_bwd_mode = mode;
+    return HSR_OK;
+}
+
+int hsr_profile_select(unsigned stage_mask)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_mask = stage_mask;
     return HSR_OK;
 }
 

@@ -91,8 +91,12 @@ int hsr_launch_scan_block_sums(int P, GeomState& g, hipStream_t stream);
 int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, uint2* ranges,
                          hipStream_t stream);  // also zeroes ranges[0, tiles)
 int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, int T, uint2* ranges, hipStream_t stream);  // also fills ranges
-bool hsr_launch_bin_tiles(int P, int R, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, uint2* ranges,
-                          hipStream_t stream);  // direct binning into (b.keys, b.vals) + ranges; false = not applicable
+struct HsrBinPlan { int nblk, per_block; };   // direct tile binning: workgroups and Gaussians per workgroup
+bool hsr_bin_plan(int P, int T, size_t scratch_words, HsrBinPlan* plan);   // false = not applicable (radix path)
+int hsr_launch_bin_count(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, uint32_t* scratch,
+                         uint2* ranges, hipStream_t stream);               // per-tile counts -> ranges (no num_rendered needed)
+int hsr_launch_bin_emit(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, const uint32_t* scratch,
+                        uint64_t* comp, hipStream_t stream);               // (depth, index) composites into the tile segments
 int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream);  // per-tile (depth, index) sort
 int hsr_sort_tile_passes(int end_bit);
 bool hsr_sort_emit_into_sorted_buffers(int end_bit);

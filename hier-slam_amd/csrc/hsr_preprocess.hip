@@ -477,31 +477,47 @@ int hsr_launch_duplicate(int P, const int* radii, int tiles_x, int tiles_y, Geom
     return HSR_OK;
 }
 
-// Direct tile binning (see bin_hist_kernel).  Scratch = the keys_unsorted array, which this path does not otherwise use
-// (8 bytes x R); returns false — caller takes the radix path — when there are too many tiles for LDS counters or R is too
-// small to hold the count table of even a few workgroups.
-bool hsr_launch_bin_tiles(int P, int R, const int* radii, int tiles_x, int tiles_y, GeomState& g, BinState& b, uint2* ranges,
-                          hipStream_t stream)
+// Direct tile binning (see bin_hist_kernel), in two halves so that the host's wait for num_rendered (it sizes the binning
+// buffer, reference rasterizer_impl.cu:285) overlaps the count phase instead of idling the GPU:
+//   hsr_launch_bin_count : needs neither num_rendered nor the binning buffer — count table in `scratch` (the caller lends
+//                          the image state's final_T array, which nothing touches before the render kernel), fills ranges;
+//   hsr_launch_bin_emit  : after the binning buffer exists, emits into its `keys` array.
+// hsr_bin_plan() decides the partition (or declines: too many tiles for LDS counters / scratch too small).
+bool hsr_bin_plan(int P, int T, size_t scratch_words, HsrBinPlan* plan)
 {
-    const int T = tiles_x * tiles_y;
-    if (T > BIN_MAX_TILES || P <= 0 || R <= 0) return false;
-    const size_t cap_words = (size_t)R * 2;                       // u32 words available in keys_unsorted
-    if (cap_words < (size_t)T * (2 + 8)) return false;
+    if (T > BIN_MAX_TILES || T <= 0 || P <= 0) return false;
+    if (scratch_words < (size_t)T * (2 + 8)) return false;
     int nblk = (P + 2047) / 2048;
-    const size_t max_blk = (cap_words - 2 * (size_t)T) / (size_t)T;
+    const size_t max_blk = (scratch_words - 2 * (size_t)T) / (size_t)T;
     if ((size_t)nblk > max_blk) nblk = (int)max_blk;
     if (nblk > 2048) nblk = 2048;
-    int per_block = ((P + nblk - 1) / nblk + BIN_THREADS - 1) & ~(BIN_THREADS - 1);   // multiple of 1024
-    nblk = (P + per_block - 1) / per_block;
-    uint32_t* table = reinterpret_cast<uint32_t*>(b.keys_unsorted);
-    uint32_t* totals = table + (size_t)nblk * T;
-    uint32_t* base = totals + T;
-    const size_t lds = (size_t)T * sizeof(uint32_t);
-    bin_hist_kernel<<<nblk, BIN_THREADS, lds, stream>>>(P, per_block, radii, tiles_x, tiles_y, g, table);
-    bin_scan_kernel<<<(T + 63) / 64, 1024, 0, stream>>>(T, nblk, table, totals);
-    bin_offsets_kernel<<<1, 1024, 0, stream>>>(T, totals, base, ranges);
-    bin_emit_kernel<<<nblk, BIN_THREADS, lds, stream>>>(P, per_block, radii, tiles_x, tiles_y, g, table, base, b.keys);
+    plan->per_block = ((P + nblk - 1) / nblk + BIN_THREADS - 1) & ~(BIN_THREADS - 1);   // multiple of 1024
+    plan->nblk = (P + plan->per_block - 1) / plan->per_block;
     return true;
+}
+
+int hsr_launch_bin_count(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, uint32_t* scratch,
+                         uint2* ranges, hipStream_t stream)
+{
+    const int T = tiles_x * tiles_y;
+    uint32_t* table = scratch;
+    uint32_t* totals = table + (size_t)plan.nblk * T;
+    uint32_t* base = totals + T;
+    bin_hist_kernel<<<plan.nblk, BIN_THREADS, (size_t)T * sizeof(uint32_t), stream>>>(P, plan.per_block, radii, tiles_x, tiles_y, g, table);
+    bin_scan_kernel<<<(T + 63) / 64, 1024, 0, stream>>>(T, plan.nblk, table, totals);
+    bin_offsets_kernel<<<1, 1024, 0, stream>>>(T, totals, base, ranges);
+    return HSR_OK;
+}
+
+int hsr_launch_bin_emit(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, const uint32_t* scratch,
+                        uint64_t* comp, hipStream_t stream)
+{
+    const int T = tiles_x * tiles_y;
+    const uint32_t* table = scratch;
+    const uint32_t* base = table + (size_t)plan.nblk * T + T;
+    bin_emit_kernel<<<plan.nblk, BIN_THREADS, (size_t)T * sizeof(uint32_t), stream>>>(P, plan.per_block, radii, tiles_x, tiles_y, g, table,
+                                                                                      base, comp);
+    return HSR_OK;
 }
 
 int hsr_launch_tile_ranges_only(int R, const uint64_t* keys, uint2* ranges, hipStream_t stream)

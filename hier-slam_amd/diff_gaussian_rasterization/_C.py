@@ -77,6 +77,8 @@ def _load():
     lib.hsr_stage_name.argtypes = [ci]
     lib.hsr_profile_enable.restype = ci
     lib.hsr_profile_enable.argtypes = [ci]
+    lib.hsr_profile_select.restype = ci
+    lib.hsr_profile_select.argtypes = [C.c_uint]
     lib.hsr_profile_read.restype = ci
     lib.hsr_profile_read.argtypes = [vp, ci]
     lib.hsr_get_state_layout.restype = ci

@@ -169,6 +169,9 @@ typedef struct hsr_profile {
     uint64_t calls[HSR_STAGE_COUNT]; /* number of timed launches (a stage may be several kernels) */
 } hsr_profile;
 int hsr_profile_enable(int on);
+/* restrict the stage timers to the stages whose bit is set (bit i = stage i; default: all).  Every timed stage costs two
+ * event records per call, which perturb a tight launch sequence; a measurement of one kernel should time only that one. */
+int hsr_profile_select(unsigned stage_mask);
 int hsr_profile_read(hsr_profile* out, int reset);
 const char* hsr_stage_name(int stage);
 
