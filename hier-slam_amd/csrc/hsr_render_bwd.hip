@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
     __shared__ uint8_t s_flat[4][256];
     __shared__ int s_wmax[4];
 
-    const int tile = blockIdx.x;
+    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const TileGeom tg = tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
 int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    const dim3 grid(tiles), block(256);
+    const dim3 grid(hsr_tile_grid(tiles)), block(256);
     // default for K <= 27: the matrix-core kernel (hsr_render_bwd_mfma.hip), half the VALU instructions of the
     // all-VALU kernels below, which serve K > 27 and HSR_BWD_IMPL=valu (A/B timing, tests).
     static const bool use_mfma = !(getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "valu"));

@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
     __shared__ int s_prev_id[4][MF_SLOTS];
     __shared__ float s_u7[4][MF_SLOTS * 8];
 
-    const int tile = blockIdx.x;
+    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const TileGeom tg = tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
 int hsr_launch_render_backward_mfma(const RenderBwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    const dim3 grid(tiles), block(256);
+    const dim3 grid(hsr_tile_grid(tiles)), block(256);
     const int K = a.semantic ? a.K : 0;
     if (K == 0) render_bwd_mfma_kernel<0><<<grid, block, 0, stream>>>(a);
     else if (K <= 11) render_bwd_mfma_kernel<11><<<grid, block, 0, stream>>>(a);   // one 16-channel group

@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(256) render_bwd_rows_kernel(RenderBwdArgs a)
     __shared__ int s_slot_id[4][MF_SLOTS];   // batch slot j of each panel row
     __shared__ float s_acc[BATCH * ROW];
 
-    const int tile = blockIdx.x;
+    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const TileGeom tg = tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
@@ -298,7 +299,7 @@ int hsr_launch_inverse_map(int R, int tiles_x, int tiles_y, const uint64_t* keys
 int hsr_launch_render_backward_rows(const RenderBwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    const dim3 grid(tiles), block(256);
+    const dim3 grid(hsr_tile_grid(tiles)), block(256);
     const int K = a.semantic ? a.K : 0;
     if (K <= 11) { render_bwd_rows_kernel<11><<<grid, block, 0, stream>>>(a); return 11; }
     if (K == 16) { render_bwd_rows_kernel<16><<<grid, block, 0, stream>>>(a); return 16; }

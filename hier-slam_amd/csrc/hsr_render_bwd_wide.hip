@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(256, 2) render_bwd_wide_kernel(RenderBwdArgs a
     __shared__ int s_prev_id[4][WF_SLOTS];
     __shared__ float s_u7[4][WF_SLOTS * 8];
 
-    const int tile = blockIdx.x;
+    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const TileGeom tg = tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
@@ -324,7 +325,7 @@ void launch_pass(const RenderBwdArgs& a, int c0, int ns, dim3 grid, hipStream_t 
 int hsr_launch_render_backward_wide(const RenderBwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    const dim3 grid(tiles);
+    const dim3 grid(hsr_tile_grid(tiles));
     const int K = a.K;
     const int first = K < WF_BASE_SEM ? K : WF_BASE_SEM;
     launch_pass<true>(a, 0, first, grid, stream);

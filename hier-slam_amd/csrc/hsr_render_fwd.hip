@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
     __shared__ uint8_t s_lcnt[4][4];
     __shared__ int s_wdone[4];
 
-    const int tile = blockIdx.x;
+    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, wv = t >> 6;
     const TileGeom tg = tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
 int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    const dim3 grid(tiles), block(256);
+    const dim3 grid(hsr_tile_grid(tiles)), block(256);
     // default for K <= 27: the per-lane kernels below.  HSR_FWD_IMPL=mfma selects the pair-pipelined matrix-core kernel
     // (hsr_render_fwd_pair.hip): parity-tested, but 0.27 vs 0.22 ms at the headline workload — the ~25 VALU instructions
     // that evaluate alpha per list entry dominate, the matrix cores only take the 15 packed FMAs behind them, and every

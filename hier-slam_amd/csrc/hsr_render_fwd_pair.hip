@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(256, 4) render_fwd_pair_kernel(RenderFwdArgs a
     __shared__ uint8_t s_flat[4][PF_BATCH + 8];
     __shared__ int s_wdone[4];
 
-    const int tile = blockIdx.x;
+    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const TileGeom tg = tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(256, 4) render_fwd_pair_kernel(RenderFwdArgs a
 bool hsr_launch_render_forward_pair(const RenderFwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    const dim3 grid(tiles), block(256);
+    const dim3 grid(hsr_tile_grid(tiles)), block(256);
     if (!a.semantic) { render_fwd_pair_kernel<0, true><<<grid, block, 0, stream>>>(a); return true; }
     if (a.K > 27) return false;
     if (a.K == 0) render_fwd_pair_kernel<0, false><<<grid, block, 0, stream>>>(a);

@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(256, 2) render_fwd_wide_kernel(RenderFwdArgs a
     __shared__ int s_wdone[4];
 
     const int K = a.K;
-    const int tile = blockIdx.x;
+    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const TileGeom tg = tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
@@ -239,7 +240,7 @@ bool hsr_launch_render_forward_wide(const RenderFwdArgs& a_, hipStream_t stream)
     a.debug_flags = dbg;
     if (!a.semantic || a.K < 29 || a.K > 124) return false;  // K + 4 channels must need 2..4 blocks of 32
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    const dim3 grid(tiles), block(256);
+    const dim3 grid(hsr_tile_grid(tiles)), block(256);
     const int nb = (a.K + 4 + 31) / 32;  // K semantic channels + r, g, b, depth
     if (nb == 2) render_fwd_wide_kernel<2><<<grid, block, 0, stream>>>(a);
     else if (nb == 3) render_fwd_wide_kernel<3><<<grid, block, 0, stream>>>(a);

@@ -24,6 +24,14 @@
 
 #define HSR_LOG2E 1.4426950408889634f
 
+// XCD-aware workgroup -> tile mapping.  The dispatcher deals workgroups round-robin to the 8 XCDs (workgroup b runs on
+// XCD b % 8) and each XCD has its own L2, so with tile = b every one of the ~1.8 tiles a splat touches pulls the splat's
+// record (and its 4K-byte semantic row) into a different L2.  Here XCD x walks the contiguous tile range
+// [x * ceil(T/8), (x+1) * ceil(T/8)) in order: horizontally and vertically adjacent tiles run on the same XCD at about the
+// same time and share those lines.  Launch hsr_tile_grid(T) workgroups; workgroups mapped past T exit at once.
+__host__ __device__ inline int hsr_tile_grid(int T) { return 8 * ((T + 7) / 8); }
+__device__ __forceinline__ int hsr_block_tile(int b, int T) { return (b & 7) * ((T + 7) >> 3) + (b >> 3); }
+
 struct TileGeom {
     int tx, ty;        // tile coordinates
     int px, py;        // this lane's pixel
