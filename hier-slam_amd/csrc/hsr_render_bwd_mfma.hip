@@ -265,6 +265,10 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
                     const int j = s_list[wv][seg * 64 + k];
                     const float4 g = s_geo[j];
                     const float2 co = s_co[j];
+                    // colour/depth of the splat fetched together with its geometry: read after the "anyone active?" branch
+                    // it would be a third dependent LDS round trip per accepted splat
+                    const float4 cd = s_col[j];
+                    asm volatile("" ::"v"(cd.x), "v"(cd.y), "v"(cd.z), "v"(cd.w));
                     const int pos = hi - 1 - j;
                     const float dx = g.x - pfx, dy = g.y - pfy;
                     const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
@@ -283,7 +287,6 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
                     panel[nslot * MF_STRIDE + lane] = w;
                     if (lane == 0) s_slot_id[wv][nslot] = s_id[j];
 
-                    const float4 cd = s_col[j];
                     const float h = fmaf(cd.x, dpx0, fmaf(cd.y, dpx1, fmaf(cd.z, dpx2, fmaf(cd.w, dpd, dpo))));
                     const float Rn = fmaf(last_alpha, last_h - Rb, Rb);
                     float dL_dalpha = (h - Rn) * test_T;
