@@ -261,8 +261,12 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
         if (hi - cnt < wmax) {  // else: this wave's pixels all stopped in front of this batch
             for (int seg = 0; seg < 4; seg++) {
                 const int m = s_lcnt[wv][seg];
+                int j_next = s_list[wv][seg * 64];
                 for (int k = 0; k < m; k++) {
-                    const int j = s_list[wv][seg * 64 + k];
+                    // the slot of the NEXT entry is fetched one iteration ahead: slot -> record is otherwise two dependent
+                    // LDS round trips per entry
+                    const int j = j_next;
+                    j_next = s_list[wv][seg * 64 + min(k + 1, 63)];
                     const float4 g = s_geo[j];
                     const float2 co = s_co[j];
                     // colour/depth of the splat fetched together with its geometry: read after the "anyone active?" branch
