@@ -238,8 +238,10 @@ __global__ void __launch_bounds__(256, 2) render_bwd_wide_kernel(RenderBwdArgs a
         if (hi - cnt < wmax) {  // else: this wave's pixels all stopped in front of this batch
             for (int seg = 0; seg < 4; seg++) {
                 const int m = s_lcnt[wv][seg];
+                int j_next = s_list[wv][seg * 64];
                 for (int k = 0; k < m; k++) {
-                    const int j = s_list[wv][seg * 64 + k];
+                    const int j = j_next;   // slot fetched one iteration ahead (slot -> record are dependent LDS round trips)
+                    j_next = s_list[wv][seg * 64 + min(k + 1, 63)];
                     const float4 g = s_geo[j];
                     const float2 co = s_co[j];
                     const int pos = hi - 1 - j;
