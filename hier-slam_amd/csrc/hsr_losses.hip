@@ -327,6 +327,216 @@ __global__ __launch_bounds__(LB) void tree_ce_kernel(const float* __restrict__ l
         for (int c = covered_end; c < K; c++) grad[(size_t)c * N + p] = 0.f;   // channels behind the last level
 }
 
+// ---------------------------------------------------------------- leaf head: 1x1-conv MLP + cross-entropy, fused
+// logits[c] = b[c] + sum_k Wt[c][k] * sem[k]  per pixel (torch.nn.Conv2d(K, C, 1), scripts/hierslam.py:1756), CrossEntropyLoss on
+// them (scripts/hierslam.py:976-983), and the three gradients.  One thread per pixel (lane = pixel):
+//   pass 1: the C logits on the fly -> online log-sum-exp;  weights are wave-uniform, i.e. scalar loads + v_fmac with an SGPR;
+//   pass 2, 16 classes at a time: logits again, g = (softmax - onehot) / count, d_sem[k] += Wt[c][k] * g  (VALU), and g goes
+//           into a per-wave LDS panel [16 classes][64 pixels];  d_Wt[c][k] = sum_pixels g[c] * sem[k] is a GEMM with the
+//           reduction over pixels, so it runs on the matrix cores: A = the panel (class, pixel), B = sem of the wave's 64
+//           pixels transposed once through LDS into B-operand layout, v_mfma_f32_16x16x4_f32 (exact fp32 fmaf chain), the
+//           C x K accumulators stay in registers over all pixels a workgroup visits.  The bias is input channel K (constant
+//           1), so d_b is column K of d_Wt.
+// Neither the [C,H,W] logits nor their gradient ever exist in memory (333 MB each at C = 102, 1200x680).
+// Workgroups are persistent (grid = a few per CU) so that the per-workgroup partial d_Wt fits a fixed-order finish.
+constexpr int LM_MAX_BLOCKS = 512;   // persistent workgroups (2 per CU)
+constexpr int LM_KP = 32;           // padded input width: K channels + bias input, K <= 31
+constexpr int LM_MAX_CT = 8;        // class tiles of 16: C <= 128
+constexpr int LM_PANEL = 64 * 17;   // floats per wave: max(16 * 66, 64 * 17)
+constexpr int LM_STRIDE = 66;
+typedef float lm_f32x4 __attribute__((ext_vector_type(4)));
+
+// KU: input columns actually multiplied (K channels + the bias input, rounded up to 4); CT: class tiles in use (<= 8)
+template <int KU>
+__global__ void __launch_bounds__(256, 2) leaf_mlp_ce_kernel(const float* __restrict__ sem, const float* __restrict__ wt /*[C][LM_KP], bias at K*/,
+                                                             const int64_t* __restrict__ labels, int N, int K, int C, int CT, int ignore_index,
+                                                             const float* __restrict__ inv_count, float* __restrict__ d_sem,
+                                                             float* __restrict__ part_loss, float* __restrict__ part_dw)
+{
+    __shared__ float s_panel[4][LM_PANEL];
+    __shared__ float s_red[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    float* panel = s_panel[wv];
+    lm_f32x4 acc[LM_MAX_CT][2];
+#pragma unroll
+    for (int ct = 0; ct < LM_MAX_CT; ct++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) acc[ct][nt] = lm_f32x4{0.f, 0.f, 0.f, 0.f};
+    float loss_acc = 0.f;
+    const float inv = inv_count[0];
+
+    for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
+        const int px = base + t;
+        const bool live = px < N;
+        const size_t p = live ? (size_t)px : 0;
+        float sv[LM_KP];
+#pragma unroll
+        for (int k = 0; k < LM_KP; k++) sv[k] = k < K ? sem[(size_t)k * N + p] : 0.f;   // unconditional loads, then masked
+#pragma unroll
+        for (int k = 0; k < LM_KP; k++) sv[k] = k < K ? (live ? sv[k] : 0.f) : (k == K && live ? 1.0f : 0.f);
+        const int64_t lab64 = labels[p];
+        const bool valid = live && lab64 != (int64_t)ignore_index;
+        const int lab = (int)lab64;
+
+        // B operand of the weight-gradient GEMM: sem of this wave's 64 pixels, two 16-channel groups
+        float Breg[2][16];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) panel[lane * 17 + c] = sv[16 * nt + c];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int m = 0; m < 16; m++) Breg[nt][m] = panel[(4 * m + (lane >> 4)) * 17 + (lane & 15)];
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // The weight row of the NEXT class is fetched (scalar loads: the address is wave-uniform) while the current class is
+        // evaluated; exponentials are v_exp_f32 on pre-scaled arguments (2 instructions instead of libm's 14 — the logits
+        // are O(10), so the extra rounding of z*log2(e) is ~1e-6 relative, inside the 1e-5 the tests ask for).
+        auto load_row = [&](int c, float (&w)[KU]) {
+            const float4* w4 = reinterpret_cast<const float4*>(wt + (size_t)min(c, CT * 16 - 1) * LM_KP);
+#pragma unroll
+            for (int q = 0; q < KU / 4; q++) {
+                const float4 x = w4[q];
+                w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+            }
+        };
+        constexpr float L2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+        // pass 1: log-sum-exp of the C logits, in base 2 (m2 = running max of z*log2e, sum of 2^(z*log2e - m2))
+        float m2 = -INFINITY, sum = 0.f, picked = 0.f;
+        {
+            auto class1 = [&](int c, const float (&w)[KU]) {
+                float z = 0.f;
+#pragma unroll
+                for (int k = 0; k < KU; k++) z = fmaf(w[k], sv[k], z);
+                picked = c == lab ? z : picked;
+                const float z2 = z * L2E;
+                const float nm = fmaxf(m2, z2);
+                sum = sum * __builtin_amdgcn_exp2f(m2 - nm) + __builtin_amdgcn_exp2f(z2 - nm);
+                m2 = nm;
+            };
+            // two register sets, ping-pong (rotating one set into the other costs a scalar move per weight per class, and a
+            // wave issues one instruction per 4 cycles whatever its type)
+            float wa[KU], wb[KU];
+            load_row(0, wa);
+            for (int c = 0; c < C; c += 2) {
+                load_row(c + 1, wb);
+                class1(c, wa);
+                load_row(c + 2, wa);
+                if (c + 1 < C) class1(c + 1, wb);
+            }
+        }
+        const float lse2 = m2 + __builtin_amdgcn_logf(sum);   // log2-sum-exp2;  lse = lse2 * ln 2
+        const float lse = lse2 * LN2;
+        loss_acc += valid ? lse - picked : 0.f;
+        const float gscale = valid ? inv : 0.f;
+
+        // pass 2: gradients.  A runtime loop over the classes (the class arithmetic exists once in the code: unrolling it
+        // per 16-class tile made hipcc keep several tiles' weights in flight and spill ~900 SGPRs); every 16th class
+        // the panel goes through the matrix cores into that tile's accumulators.
+        float ds[LM_KP];
+#pragma unroll
+        for (int k = 0; k < LM_KP; k++) ds[k] = 0.f;
+        {
+            auto class2 = [&](int c, const float (&w)[KU]) {
+                float z = 0.f;
+#pragma unroll
+                for (int k = 0; k < KU; k++) z = fmaf(w[k], sv[k], z);
+                // rows >= C of the packed weights are zero: z = 0 there, and the class must not contribute
+                const float g = c < C ? (__builtin_amdgcn_exp2f(fmaf(z, L2E, -lse2)) - (c == lab ? 1.f : 0.f)) * gscale : 0.f;
+#pragma unroll
+                for (int k = 0; k < KU; k++) ds[k] = fmaf(w[k], g, ds[k]);
+                panel[(c & 15) * LM_STRIDE + lane] = g;
+                if ((c & 15) == 15) {
+                    __builtin_amdgcn_wave_barrier();
+                    const float* arow = panel + (lane & 15) * LM_STRIDE + (lane >> 4);
+                    float av[16];
+#pragma unroll
+                    for (int m = 0; m < 16; m++) av[m] = arow[4 * m];
+#pragma unroll
+                    for (int ct = 0; ct < LM_MAX_CT; ct++)
+                        if (ct == (c >> 4)) {   // wave-uniform: static accumulator index
+#pragma unroll
+                            for (int m = 0; m < 16; m++) {
+                                acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], Breg[0][m], acc[ct][0], 0, 0, 0);
+                                acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], Breg[1][m], acc[ct][1], 0, 0, 0);
+                            }
+                        }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            };
+            float wa[KU], wb[KU];
+            load_row(0, wa);
+            for (int c = 0; c < CT * 16; c += 2) {
+                load_row(c + 1, wb);
+                class2(c, wa);
+                load_row(c + 2, wa);
+                class2(c + 1, wb);
+            }
+        }
+        if (live && d_sem)
+#pragma unroll
+            for (int k = 0; k < LM_KP; k++)
+                if (k < K) d_sem[(size_t)k * N + p] = ds[k];
+    }
+
+    // ---- per-workgroup partials: loss, then d_Wt[c][k] summed over the four waves in a fixed order ----
+    const float tot = block_sum(loss_acc, s_red);
+    if (t == 0) part_loss[blockIdx.x] = tot;
+    float* out = part_dw + (size_t)blockIdx.x * (CT * 16 * LM_KP);
+#pragma unroll
+    for (int ct = 0; ct < LM_MAX_CT; ct++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            if (ct >= CT) break;   // uniform
+            // D[row = 4*(lane>>4) + r][col = lane&15]: class 16ct + row, input channel 16nt + col
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; r++) panel[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = acc[ct][nt][r];
+            __syncthreads();
+            {
+                const int row = t >> 4, col = t & 15;   // 256 threads = 16 x 16 outputs
+                const float v = ((s_panel[0][row * 17 + col] + s_panel[1][row * 17 + col]) + s_panel[2][row * 17 + col]) +
+                                s_panel[3][row * 17 + col];
+                out[(size_t)(16 * ct + row) * LM_KP + 16 * nt + col] = v;
+            }
+        }
+}
+
+// weights [C][K] + bias [C] -> rows of LM_KP floats: Wt[c][k<K] = weight, Wt[c][K] = bias, 0 elsewhere (rows >= C zero)
+__global__ __launch_bounds__(256) void leaf_pack_weights_kernel(const float* __restrict__ weight, const float* __restrict__ bias, int K, int C,
+                                                                int rows, float* __restrict__ wt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * LM_KP) return;
+    const int c = i / LM_KP, k = i - c * LM_KP;
+    wt[i] = c < C ? (k < K ? weight[(size_t)c * K + k] : (k == K ? bias[c] : 0.f)) : 0.f;
+}
+
+// d_weight[c][k], d_bias[c] = fixed-order sum over the workgroup partials (double): 32 outputs x 8 partial-groups per
+// workgroup, groups combined through LDS in index order
+__global__ __launch_bounds__(256) void leaf_finish_dw_kernel(const float* __restrict__ part_dw, int nblk, int per, int K, int C,
+                                                             float* __restrict__ d_weight, float* __restrict__ d_bias)
+{
+    __shared__ double s_acc[8][33];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
+    double acc = 0.0;
+    if (i < per)
+        for (int b = grp; b < nblk; b += 8) acc += (double)part_dw[(size_t)b * per + i];
+    s_acc[grp][o] = acc;
+    __syncthreads();
+    if (grp != 0 || i >= per) return;
+    double tot = 0.0;
+#pragma unroll
+    for (int g2 = 0; g2 < 8; g2++) tot += s_acc[g2][o];
+    const int c = i / LM_KP, k = i - c * LM_KP;
+    if (c >= C || k > K) return;
+    if (k < K) { if (d_weight) d_weight[(size_t)c * K + k] = (float)tot; }
+    else if (d_bias) d_bias[c] = (float)tot;
+}
+
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int check_scratch(const char* what, char* scratch, size_t have, size_t need)
@@ -352,6 +562,9 @@ extern "C" size_t hsr_loss_scratch_bytes(int channels, int H, int W)
     const size_t l1 = 2 * align256((size_t)channels * blocks * sizeof(float)) + 256;
     if (ce > need) need = ce;
     if (l1 > need) need = l1;
+    const size_t leaf = (size_t)LM_MAX_BLOCKS * (LM_MAX_CT * 16 * LM_KP + 4) * sizeof(float) + 2 * align256(blocks * sizeof(float)) +
+                        (size_t)LM_MAX_CT * 16 * LM_KP * sizeof(float) + 4096;
+    if (leaf > need) need = leaf;
     return need + 1024;
 }
 
@@ -476,6 +689,52 @@ extern "C" int hsr_loss_tree_ce(int K, int H, int W, int num_levels, const int* 
     count_finish_kernel<<<1, LB, 0, stream>>>(cparts, nb, HSR_LOSS_MAX_LEVELS, num_levels, inv);
     tree_ce_kernel<<<nb, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, inv, out_grad, partials);
     finish_kernel<<<1, LB, 0, stream>>>(partials, nb, HSR_LOSS_MAX_LEVELS, num_levels, inv, 1.0f, out_level_loss);
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+extern "C" int hsr_loss_leaf_mlp_ce(int K, int C, int H, int W, const float* sem, const float* weight, const float* bias,
+                                    const int64_t* labels, int ignore_index, float* out_loss, float* d_sem, float* d_weight,
+                                    float* d_bias, char* scratch, size_t scratch_bytes, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (K < 1 || K > LM_KP - 1 || C < 1 || C > 16 * LM_MAX_CT) {
+        hsr_set_error("loss_leaf_mlp_ce: supports 1 <= K <= %d input channels and 1 <= C <= %d classes (got K=%d C=%d)", LM_KP - 1,
+                      16 * LM_MAX_CT, K, C);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (H < 1 || W < 1 || (size_t)H * W > 0x7fffffffu || !sem || !weight || !bias || !labels || !out_loss) {
+        hsr_set_error("loss_leaf_mlp_ce: invalid sizes H=%d W=%d or NULL sem/weight/bias/labels/out_loss", H, W);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    const int N = H * W;
+    const int CT = (C + 15) / 16;
+    int nblk = (N + 255) / 256;
+    if (nblk > LM_MAX_BLOCKS) nblk = LM_MAX_BLOCKS;
+    const int nb_cnt = (N + LB * L1_ITEMS - 1) / (LB * L1_ITEMS);
+    // scratch: packed weights [CT*16][32] | inv count | count partials | loss partials | dW partials [nblk][CT*16*32]
+    const size_t wt_bytes = align256((size_t)CT * 16 * LM_KP * sizeof(float));
+    const size_t cnt_bytes = align256((size_t)nb_cnt * sizeof(unsigned));
+    const size_t loss_bytes = align256((size_t)nblk * sizeof(float));
+    const size_t dw_bytes = (size_t)nblk * CT * 16 * LM_KP * sizeof(float);
+    int rc = check_scratch("loss_leaf_mlp_ce", scratch, scratch_bytes, wt_bytes + 256 + cnt_bytes + loss_bytes + dw_bytes);
+    if (rc != HSR_OK) return rc;
+    float* wt = reinterpret_cast<float*>(scratch);
+    float* inv = reinterpret_cast<float*>(scratch + wt_bytes);
+    unsigned* cparts = reinterpret_cast<unsigned*>(scratch + wt_bytes + 256);
+    float* part_loss = reinterpret_cast<float*>(scratch + wt_bytes + 256 + cnt_bytes);
+    float* part_dw = reinterpret_cast<float*>(scratch + wt_bytes + 256 + cnt_bytes + loss_bytes);
+    leaf_pack_weights_kernel<<<(CT * 16 * LM_KP + 255) / 256, 256, 0, stream>>>(weight, bias, K, C, CT * 16, wt);
+    ce_count_kernel<<<(N + LB - 1) / LB, LB, 0, stream>>>(labels, N, 1, ignore_index, reinterpret_cast<unsigned*>(part_dw));
+    count_finish_kernel<<<1, LB, 0, stream>>>(reinterpret_cast<unsigned*>(part_dw), (N + LB - 1) / LB, HSR_LOSS_MAX_LEVELS, 1, inv);
+    (void)cparts;
+    const int ku = (K + 1 + 3) & ~3;
+    if (ku <= 20) leaf_mlp_ce_kernel<20><<<nblk, 256, 0, stream>>>(sem, wt, labels, N, K, C, CT, ignore_index, inv, d_sem, part_loss, part_dw);
+    else if (ku <= 28) leaf_mlp_ce_kernel<28><<<nblk, 256, 0, stream>>>(sem, wt, labels, N, K, C, CT, ignore_index, inv, d_sem, part_loss, part_dw);
+    else leaf_mlp_ce_kernel<32><<<nblk, 256, 0, stream>>>(sem, wt, labels, N, K, C, CT, ignore_index, inv, d_sem, part_loss, part_dw);
+    finish_kernel<<<1, LB, 0, stream>>>(part_loss, nblk, 1, 1, inv, 1.0f, out_loss);
+    if (d_weight || d_bias)
+        leaf_finish_dw_kernel<<<(CT * 16 * LM_KP + 31) / 32, 256, 0, stream>>>(part_dw, nblk, CT * 16 * LM_KP, K, C, d_weight, d_bias);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
 }

@@ -29,7 +29,11 @@ _lib.hsr_loss_ssim.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
 _lib.hsr_loss_tree_ce.restype = _ci
 _lib.hsr_loss_tree_ce.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), C.POINTER(C.c_float), _vp, _vp, _ci, _vp, _vp, _vp, _sz, _vp]
 
+_lib.hsr_loss_leaf_mlp_ce.restype = _ci
+_lib.hsr_loss_leaf_mlp_ce.argtypes = [_ci, _ci, _ci, _ci] + [_vp] * 4 + [_ci] + [_vp] * 5 + [_sz, _vp]
+
 SUM, MEAN = 0, 1
+LEAF_MAX_K, LEAF_MAX_C = 31, 128
 _weight_cache = {}
 
 
@@ -181,3 +185,58 @@ def cross_entropy_planar(logits, labels, ignore_index=-100):
     (flat classes: scripts/hierslam.py:947-954; leaf MLP output: :976-983)."""
     z = logits[0] if logits.dim() == 4 else logits
     return tree_cross_entropy(z, labels.reshape(1, z.shape[-2], z.shape[-1]), (z.shape[0],), None, ignore_index)
+
+
+class _LeafMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sem, weight, bias, labels, ignore_index):
+        z = _chw(sem, "im_semantic")
+        K, H, W = z.shape
+        dev = z.device
+        w = _dev2(weight.reshape(weight.shape[0], -1), "weight")
+        C = w.shape[0]
+        if w.shape[1] != K or bias.numel() != C:
+            raise RuntimeError("hsr_utils.losses: weight %s / bias %s do not match %d input channels" % (tuple(weight.shape), tuple(bias.shape), K))
+        b = _dev2(bias.reshape(-1), "bias")
+        lab = labels.reshape(H, W).to(device=dev, dtype=torch.int64).contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        need = (sem.requires_grad, weight.requires_grad, bias.requires_grad)
+        d_sem = torch.empty_like(z) if need[0] else None
+        d_w = torch.empty_like(w) if (need[1] or need[2]) else None
+        d_b = torch.empty_like(b) if (need[1] or need[2]) else None
+        sc = _scratch(K, H, W, dev)
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_leaf_mlp_ce(K, C, H, W, z.data_ptr(), w.data_ptr(), b.data_ptr(), lab.data_ptr(), int(ignore_index),
+                                           out.data_ptr(), None if d_sem is None else d_sem.data_ptr(), None if d_w is None else d_w.data_ptr(),
+                                           None if d_b is None else d_b.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev))
+        if rc < 0:
+            _glue._fail(rc, "hsr_loss_leaf_mlp_ce")
+        ctx.grads = (None if d_sem is None else d_sem.view(sem.shape), None if d_w is None else d_w.view(weight.shape),
+                     None if d_b is None else d_b.view(bias.shape))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ds, dw, db = ctx.grads
+        return (None if ds is None else ds * g, None if dw is None else dw * g, None if db is None else db * g, None, None)
+
+
+def _dev2(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("hsr_utils.losses: %s must live on a HIP device (got %s); there is no CPU path" % (what, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("hsr_utils.losses: %s must be float32 (got %s)" % (what, t.dtype))
+    return t.contiguous()
+
+
+def leaf_mlp_cross_entropy(im_semantic, mlp, labels, ignore_index=-100):
+    """CrossEntropyLoss()(MLP_func(im_semantic.unsqueeze(0)) as [H*W, C], labels.view(-1).long()) with MLP_func a
+    torch.nn.Conv2d(K, C, kernel_size=1) (scripts/hierslam.py:1756, :976-983), value and gradients to im_semantic,
+    mlp.weight and mlp.bias from ONE kernel that never materialises the [C,H,W] logits.  `mlp` may also be a
+    (weight, bias) pair.  Wider heads (K > 31 or C > 128) run the conv in torch and the fused planar cross-entropy."""
+    weight, bias = (mlp.weight, mlp.bias) if hasattr(mlp, "weight") else mlp
+    K = im_semantic.shape[-3]
+    if K > LEAF_MAX_K or weight.shape[0] > LEAF_MAX_C:
+        logits = torch.nn.functional.conv2d(im_semantic.reshape(1, K, *im_semantic.shape[-2:]), weight.reshape(weight.shape[0], K, 1, 1), bias)
+        return cross_entropy_planar(logits, labels, ignore_index)
+    return _LeafMLP.apply(im_semantic, weight, bias, labels, ignore_index)

@@ -56,6 +56,15 @@ int hsr_loss_tree_ce(int K, int H, int W, int num_levels, const int* level_sizes
                      const int64_t* labels, int ignore_index, float* out_level_loss, float* out_grad, char* scratch,
                      size_t scratch_bytes, void* stream);
 
+/* Leaf head, fused: logits = Conv2d(K, C, kernel_size=1)(sem) (weight [C,K] = the conv's [C,K,1,1], bias [C];
+ * scripts/hierslam.py:1756), loss = CrossEntropyLoss()(logits as [H*W, C], labels) (scripts/hierslam.py:976-983), and the
+ * gradients d loss / d sem ([K,H,W]), d weight ([C,K]), d bias ([C]) — each may be NULL.  The [C,H,W] logits are never
+ * materialised.  Supports K <= 31 and C <= 128 (returns HSR_ERR_INVALID_ARGUMENT beyond: use the conv + hsr_loss_tree_ce
+ * composition).  labels: int64 [H,W].  Scratch: hsr_loss_scratch_bytes(K, H, W). */
+int hsr_loss_leaf_mlp_ce(int K, int C, int H, int W, const float* sem, const float* weight, const float* bias, const int64_t* labels,
+                         int ignore_index, float* out_loss, float* d_sem, float* d_weight, float* d_bias, char* scratch,
+                         size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,3 +112,25 @@ def tree_cross_entropy(logits, labels, level_sizes, ignore_index=-100):
             grad[begin:begin + n_l] = (sm * valid / cnt).reshape(n_l, H, W)
         begin += n_l
     return np.array(losses), grad
+
+
+def leaf_mlp_cross_entropy(sem, weight, bias, labels, ignore_index=-100):
+    """logits = Conv2d(K, C, 1)(sem) (scripts/hierslam.py:1756, :976-978), CrossEntropyLoss()(logits as [H*W, C], labels)
+    (:979-982).  sem [K,H,W], weight [C,K], bias [C], labels [H,W].  Returns (loss, d_sem, d_weight, d_bias)."""
+    s_ = np.asarray(sem, np.float64)
+    K, H, W = s_.shape
+    w, b = np.asarray(weight, np.float64).reshape(-1, K), np.asarray(bias, np.float64)
+    x = s_.reshape(K, -1)
+    z = w @ x + b[:, None]
+    lab = np.asarray(labels).reshape(-1).astype(np.int64)
+    valid = lab != ignore_index
+    cnt = int(valid.sum())
+    m = z.max(axis=0)
+    e = np.exp(z - m)
+    lse = m + np.log(e.sum(axis=0))
+    safe = np.where(valid, lab, 0)
+    loss = ((lse - z[safe, np.arange(z.shape[1])]) * valid).sum() / cnt if cnt else float("nan")
+    g = e / e.sum(axis=0)
+    g[safe, np.arange(z.shape[1])] -= 1.0
+    g = g * valid / cnt if cnt else np.zeros_like(g)
+    return loss, (w.T @ g).reshape(K, H, W), g @ x.T, g.sum(axis=1)

@@ -65,6 +65,23 @@ def main():
     total.backward()
     np.savez_compressed(os.path.join(HERE, "loss_tree_ce.npz"), logits=logits, labels=labels, level_sizes=np.array(level_sizes),
                         per_level=np.array(per_level), grad=tz.grad.numpy())
+    # leaf head: torch.nn.Conv2d(K, C, kernel_size=1) + CrossEntropyLoss exactly as scripts/hierslam.py:976-983 chains them
+    K, C, H, W = 26, 102, 20, 36
+    sem = g.normal(0, 1.5, (K, H, W)).astype(np.float32)
+    mlp = torch.nn.Conv2d(K, C, kernel_size=1)
+    with torch.no_grad():
+        mlp.weight.copy_(torch.tensor(g.normal(0, 0.3, (C, K, 1, 1)).astype(np.float32)))
+        mlp.bias.copy_(torch.tensor(g.normal(0, 0.2, (C,)).astype(np.float32)))
+    lab = g.integers(0, C, (H, W)).astype(np.int64)
+    lab[:2, :7] = -100
+    ts = torch.tensor(sem, requires_grad=True)
+    logits = mlp(ts.unsqueeze(0))
+    logits = logits.squeeze(0).view(logits.shape[1], -1).permute(1, 0)
+    loss = torch.nn.CrossEntropyLoss()(logits, torch.tensor(lab).view(-1).long())
+    loss.backward()
+    np.savez_compressed(os.path.join(HERE, "loss_leaf_mlp.npz"), sem=sem, weight=mlp.weight.detach().numpy().reshape(C, K),
+                        bias=mlp.bias.detach().numpy(), labels=lab, loss=loss.detach().numpy(), d_sem=ts.grad.numpy(),
+                        d_weight=mlp.weight.grad.numpy().reshape(C, K), d_bias=mlp.bias.grad.numpy())
     print("written", sorted(os.listdir(HERE)))
 
 

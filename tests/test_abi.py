@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
             "hsr_required_geometry_bytes", "hsr_required_image_bytes", "hsr_required_binning_bytes", "hsr_last_error",
             "hsr_version", "hsr_get_state_layout", "hsr_profile_enable", "hsr_profile_read", "hsr_stage_name",
             "hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes",
-            "hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_scratch_bytes"} <= set(protos)
+            "hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes"} <= set(protos)
     lib = C.CDLL(_C._LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), "libhsr_rast.so does not export %s" % name
@@ -49,7 +49,7 @@ def test_ctypes_signatures_match_header():
         fn = getattr(slam_helpers._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
     from hsr_utils import losses
-    for name in ("hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_scratch_bytes"):
+    for name in ("hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes"):
         fn = getattr(losses._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
 
@@ -92,6 +92,8 @@ def test_argument_validation_without_gpu():
     assert lib.hsr_loss_l1(0, 8, 8, null, null, null, 0, null, null, null, 0, null) == -1 and b"loss_l1" in lib.hsr_last_error()
     assert lib.hsr_loss_ssim(3, 0, 8, null, null, null, null, null, 0, null) == -1
     assert lib.hsr_loss_tree_ce(4, 8, 8, 1, None, None, null, null, -100, null, null, null, 0, null) == -1
+    assert lib.hsr_loss_leaf_mlp_ce(40, 10, 8, 8, null, null, null, null, -100, null, null, null, null, null, 0, null) == -1
+    assert b"K <= 31" in lib.hsr_last_error()
 
 
 def test_no_cpu_fallback_and_reference_error_messages():

@@ -217,3 +217,59 @@ def test_losses_chained_behind_the_rasterizer():
     assert abs(la - lb) < 1e-5 * max(1.0, abs(lb))
     for k in ga:
         assert _relmax(ga[k].cpu().numpy(), gb[k].cpu().numpy()) < 1e-3, k
+
+
+def test_leaf_mlp_head_matches_torch_fixture():
+    from hsr_utils import losses as L
+    d = np.load(os.path.join(GOLD, "loss_leaf_mlp.npz"))
+    sem = torch.tensor(d["sem"], device="cuda", requires_grad=True)
+    mlp = torch.nn.Conv2d(d["sem"].shape[0], d["weight"].shape[0], kernel_size=1).cuda()
+    with torch.no_grad():
+        mlp.weight.copy_(torch.tensor(d["weight"]).view_as(mlp.weight))
+        mlp.bias.copy_(torch.tensor(d["bias"]))
+    loss = L.leaf_mlp_cross_entropy(sem, mlp, torch.tensor(d["labels"], device="cuda"))
+    loss.backward()
+    assert abs(float(loss) - float(d["loss"])) < 5e-6
+    assert _relmax(sem.grad.cpu().numpy(), d["d_sem"]) < 1e-5
+    assert _relmax(mlp.weight.grad.cpu().numpy().reshape(d["d_weight"].shape), d["d_weight"]) < 1e-5
+    assert _relmax(mlp.bias.grad.cpu().numpy(), d["d_bias"]) < 1e-5
+
+
+@pytest.mark.parametrize("K,C,H,W", [(16, 41, 33, 47), (26, 102, 64, 80), (5, 3, 17, 9), (31, 128, 24, 40), (8, 17, 300, 500)])
+def test_leaf_mlp_head_against_oracle(K, C, H, W):
+    import loss_oracle as LO
+    from hsr_utils import losses as L
+    g = np.random.default_rng(K * C)
+    sem = g.normal(0, 1.5, (K, H, W)).astype(np.float32)
+    w, b = g.normal(0, 0.4, (C, K)).astype(np.float32), g.normal(0, 0.3, (C,)).astype(np.float32)
+    lab = g.integers(0, C, (H, W)).astype(np.int64)
+    lab[0, :5] = -100
+    ts = torch.tensor(sem, device="cuda", requires_grad=True)
+    tw = torch.tensor(w.reshape(C, K, 1, 1), device="cuda", requires_grad=True)
+    tb = torch.tensor(b, device="cuda", requires_grad=True)
+    loss = L.leaf_mlp_cross_entropy(ts, (tw, tb), torch.tensor(lab, device="cuda"))
+    (2.0 * loss).backward()
+    lo, ds, dw, db = LO.leaf_mlp_cross_entropy(sem, w, b, lab)
+    assert abs(float(loss) - lo) < 5e-6 * max(1.0, abs(lo))
+    assert _relmax(ts.grad.cpu().numpy(), 2 * ds) < 1e-5
+    assert _relmax(tw.grad.cpu().numpy().reshape(C, K), 2 * dw) < 2e-5      # sums over up to 150k pixels in fp32 partials
+    assert _relmax(tb.grad.cpu().numpy(), 2 * db) < 2e-5
+    # reproducible bit for bit (fixed partition, fixed-order finish)
+    ts2 = torch.tensor(sem, device="cuda", requires_grad=True)
+    tw2 = tw.detach().clone().requires_grad_(True)
+    loss2 = L.leaf_mlp_cross_entropy(ts2, (tw2, tb.detach().clone().requires_grad_(True)), torch.tensor(lab, device="cuda"))
+    (2.0 * loss2).backward()
+    assert torch.equal(loss, loss2) and torch.equal(tw.grad, tw2.grad) and torch.equal(ts.grad, ts2.grad)
+
+
+def test_leaf_mlp_head_wide_falls_back_to_conv_plus_fused_ce():
+    from hsr_utils import losses as L
+    K, C, H, W = 40, 150, 20, 30
+    g = torch.Generator().manual_seed(0)
+    sem = torch.randn(K, H, W, generator=g).cuda().requires_grad_(True)
+    mlp = torch.nn.Conv2d(K, C, kernel_size=1).cuda()
+    lab = torch.randint(0, C, (H, W), generator=g).cuda()
+    loss = L.leaf_mlp_cross_entropy(sem, mlp, lab)
+    loss.backward()
+    ref = torch.nn.functional.cross_entropy(mlp(sem.detach().unsqueeze(0)).squeeze(0).view(C, -1).permute(1, 0), lab.view(-1))
+    assert abs(float(loss) - float(ref)) < 1e-5 and sem.grad is not None and mlp.weight.grad is not None

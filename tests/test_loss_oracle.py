@@ -56,3 +56,11 @@ def test_masked_l1_matches_torch_indexing(reduction):
     loss, grad = LO.masked_l1(pred, gt, mask, reduction)
     assert abs(loss - float(ref)) <= 1e-5 * abs(float(ref))
     np.testing.assert_allclose(grad, tp.grad.numpy(), rtol=1e-6, atol=1e-12)
+
+
+def test_leaf_mlp_head_matches_torch_fixture():
+    d = np.load(os.path.join(GOLD, "loss_leaf_mlp.npz"))
+    loss, ds, dw, db = LO.leaf_mlp_cross_entropy(d["sem"], d["weight"], d["bias"], d["labels"])
+    assert abs(loss - float(d["loss"])) < 2e-6
+    for got, key in ((ds, "d_sem"), (dw, "d_weight"), (db, "d_bias")):
+        assert np.abs(got - d[key]).max() <= 3e-6 * np.abs(d[key]).max(), key

@@ -32,6 +32,9 @@ def measure(H=680, W=1200, iters=30, cpu=True):
     gt_im, gt_d = torch.rand(3, H, W, generator=g).cuda(), (torch.rand(1, H, W, generator=g) * 5).cuda()
     gt_d[0, :20] = 0
     lab = torch.stack([torch.randint(0, n, (H, W), generator=g) for n in sizes]).cuda()
+    C_leaf = 102
+    mlp = torch.nn.Conv2d(K, C_leaf, kernel_size=1).cuda()
+    leaf_lab = torch.randint(0, C_leaf, (H, W), generator=g).cuda()
     w1 = torch.tensor([np.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
     w1 = (w1 / w1.sum()).unsqueeze(1)
     win = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0).expand(3, 1, 11, 11).contiguous().cuda()
@@ -67,7 +70,7 @@ def measure(H=680, W=1200, iters=30, cpu=True):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
-            for v in (im, depth, sem):
+            for v in (im, depth, sem, *mlp.parameters()):
                 v.grad = None
             fn()
         torch.cuda.synchronize()
@@ -79,6 +82,28 @@ def measure(H=680, W=1200, iters=30, cpu=True):
            # maps read + gradients written: colour L1 3*3, SSIM fwd 3*(2+3) + bwd 3*(3+2+1), depth 3+1, CE K*3 + 8*levels
            "alg_bytes": N * (4 * (9 + 15 + 18 + 3 + 3 * K) + 1 + 8 * len(sizes))}
     out["fused_alg_GBps"] = out["alg_bytes"] / (out["fused_ms"] * 1e-3) / 1e9
+    # leaf head (scripts/hierslam.py:976-983): 1x1-conv MLP K -> 102 classes + cross-entropy; the conv stays torch (rocBLAS /
+    # MIOpen GEMM), the CE on its planar output is the fused kernel (no [H*W, C] permute copy)
+    def leaf_fused():
+        loss = L.cross_entropy_planar(mlp(sem.unsqueeze(0)), leaf_lab)
+        loss.backward()
+        return loss
+
+    def leaf_eager():
+        logits = mlp(sem.unsqueeze(0))
+        logits = logits.squeeze(0).view(logits.shape[1], -1).permute(1, 0)
+        loss = torch.nn.CrossEntropyLoss()(logits, leaf_lab.view(-1).long())
+        loss.backward()
+        return loss
+    def leaf_fully_fused():
+        loss = L.leaf_mlp_cross_entropy(sem, mlp, leaf_lab)
+        loss.backward()
+        return loss
+    out["leaf_head_fused_ms"] = timeit(leaf_fully_fused)
+    out["leaf_loss_fully_fused"] = float(leaf_fully_fused().detach())
+    out["leaf_head_fused_ce_ms"] = timeit(leaf_fused)
+    out["leaf_head_eager_ms"] = timeit(leaf_eager)
+    out["leaf_loss_fused"], out["leaf_loss_eager"] = float(leaf_fused().detach()), float(leaf_eager().detach())
     if cpu:
         import loss_oracle as LO
         t0 = time.perf_counter()
