@@ -37,6 +37,8 @@ def measure(P=500000, W=1200, H=680, iters=20):
     params["cam_trans"] = torch.zeros(1, 3, 4).cuda().requires_grad_(True)
     gt_im, gt_d = torch.rand(3, H, W, generator=g).cuda(), (torch.rand(1, H, W, generator=g) * 5 + 0.5).cuda()
     lab = torch.stack([torch.randint(0, n, (H, W), generator=g) for n in sizes]).cuda()
+    mlp = torch.nn.Conv2d(K, 102, kernel_size=1).cuda()          # MLP_func, scripts/hierslam.py:1756
+    leaf_lab = torch.randint(0, 102, (H, W), generator=g).cuda()
     w1 = torch.tensor([np.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
     w1 = (w1 / w1.sum()).unsqueeze(1)
     win = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0).expand(3, 1, 11, 11).contiguous().cuda()
@@ -62,13 +64,15 @@ def measure(P=500000, W=1200, H=680, iters=20):
         s12 = F.conv2d(a * b, win, padding=5, groups=3) - mu1 * mu2
         return (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1.pow(2) + mu2.pow(2) + 1e-4) * (s1 + s2 + 9e-4))).mean()
 
-    def iteration(fused):
+    def iteration(fused, leaf=False):
         rv = SH.transformed_params2rendervar_semantic(params, SH.transform_to_frame(params, 1, True, False)) if fused else eager_prep(params, 1)
         rv['means2D'].retain_grad()
         im, radius, sem, depth, med, opac = GaussianRasterizer_semantic(raster_settings=cam)(**rv)
         mask = ((gt_d > 0) & ~torch.isnan(depth)).detach()
         if fused:
             loss = 0.5 * L.mapping_image_loss(im, gt_im) + L.masked_l1(depth, gt_d, mask, "mean") + 0.1 * L.tree_cross_entropy(sem, lab, sizes)
+            if leaf:
+                loss = loss + 0.5 * L.leaf_mlp_cross_entropy(sem, mlp, leaf_lab)
         else:
             ce, b = 0.0, 0
             celoss = torch.nn.CrossEntropyLoss()
@@ -77,23 +81,30 @@ def measure(P=500000, W=1200, H=680, iters=20):
                 ce = ce + celoss(lvl.reshape(-1, n), lab[i].view(-1).long())
                 b += n
             loss = 0.5 * (0.8 * torch.abs(im - gt_im).mean() + 0.2 * (1.0 - eager_ssim(im, gt_im))) + torch.abs(gt_d - depth)[mask].mean() + 0.1 * ce
+            if leaf:
+                logits = mlp(sem.unsqueeze(0))
+                logits = logits.squeeze(0).view(logits.shape[1], -1).permute(1, 0)
+                loss = loss + 0.5 * celoss(logits, leaf_lab.view(-1).long())
         loss.backward()
         return loss
 
-    def timeit(fused):
+    def timeit(fused, leaf=False):
         for _ in range(3):
-            iteration(fused)
+            iteration(fused, leaf)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
-            for v in params.values():
+            for v in list(params.values()) + list(mlp.parameters()):
                 v.grad = None
-            iteration(fused)
+            iteration(fused, leaf)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters * 1e3
     lf, le = float(iteration(True).detach()), float(iteration(False).detach())
     return {"workload": "mapping iteration without optimizer: prep + semantic render + mapping losses + backward, %dx%d, P=%d, K=%d" % (W, H, P, K),
-            "fused_ms": timeit(True), "eager_around_same_rasterizer_ms": timeit(False), "loss_fused": lf, "loss_eager": le}
+            "fused_ms": timeit(True), "eager_around_same_rasterizer_ms": timeit(False), "loss_fused": lf, "loss_eager": le,
+            "with_leaf_head": {"note": "mapping iterations >= 14 add the 1x1-conv leaf MLP + cross-entropy (scripts/hierslam.py:975-983)",
+                               "fused_ms": timeit(True, True), "eager_around_same_rasterizer_ms": timeit(False, True),
+                               "loss_fused": float(iteration(True, True).detach()), "loss_eager": float(iteration(False, True).detach())}}
 
 
 if __name__ == "__main__":
