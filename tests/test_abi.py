@@ -10,7 +10,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "hsr_rasterizer.h")
-HEADERS = [HEADER, os.path.join(ROOT, "include", "hsr_frame_prep.h"), os.path.join(ROOT, "include", "hsr_losses.h")]
+HEADERS = [HEADER, os.path.join(ROOT, "include", "hsr_frame_prep.h"), os.path.join(ROOT, "include", "hsr_losses.h"),
+           os.path.join(ROOT, "include", "hsr_densify.h")]
 
 
 def _prototypes():
@@ -31,7 +32,7 @@ def test_library_exports_every_declared_symbol():
             "hsr_required_geometry_bytes", "hsr_required_image_bytes", "hsr_required_binning_bytes", "hsr_last_error",
             "hsr_version", "hsr_get_state_layout", "hsr_profile_enable", "hsr_profile_read", "hsr_stage_name",
             "hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes",
-            "hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes"} <= set(protos)
+            "hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes", "hsr_densify_frame", "hsr_densify_scratch_bytes"} <= set(protos)
     lib = C.CDLL(_C._LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), "libhsr_rast.so does not export %s" % name
@@ -47,6 +48,10 @@ def test_ctypes_signatures_match_header():
     from hsr_utils import slam_helpers
     for name in ("hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes"):
         fn = getattr(slam_helpers._lib, name)
+        assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
+    from hsr_utils import densify
+    for name in ("hsr_densify_frame", "hsr_densify_scratch_bytes"):
+        fn = getattr(densify._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
     from hsr_utils import losses
     for name in ("hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes"):
@@ -94,6 +99,9 @@ def test_argument_validation_without_gpu():
     assert lib.hsr_loss_tree_ce(4, 8, 8, 1, None, None, null, null, -100, null, null, null, 0, null) == -1
     assert lib.hsr_loss_leaf_mlp_ce(40, 10, 8, 8, null, null, null, null, -100, null, null, null, null, null, 0, null) == -1
     assert b"K <= 31" in lib.hsr_last_error()
+    from hsr_utils import densify  # sets the argtypes of the densification entry points
+    assert densify._lib.hsr_densify_scratch_bytes(680, 1200) > 680 * 1200 // 256 * 4
+    assert lib.hsr_densify_frame(0, 8, *([null] * 4), 1.0, 1.0, 0.0, 0.0, null, 0.5, 50.0, 0, *([null] * 7), null, 0, null) == -1
 
 
 def test_no_cpu_fallback_and_reference_error_messages():
