@@ -268,7 +268,9 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
     // all-VALU kernels below, which serve K > 27 and HSR_BWD_IMPL=valu (A/B timing, tests).
     static const bool use_mfma = !(getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "valu"));
     if (use_mfma && (a.semantic ? a.K : 0) <= 27) {  // one matrix-core launch covers the base sums + K <= 27 channels
-        hsr_launch_render_backward_mfma(a, stream);
+        static const bool use_mom = getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "mom");
+        if (use_mom && a.grow) hsr_launch_render_backward_mom(a, stream);
+        else hsr_launch_render_backward_mfma(a, stream);
         return HSR_OK;
     }
     if (use_mfma && a.semantic && a.K > 27) {  // wide trees: matrix-core passes of <= 64 channels (hsr_render_bwd_wide.hip)

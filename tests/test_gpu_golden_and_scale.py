@@ -155,10 +155,11 @@ def test_parity_other_accumulation_modes(name, mode):
         _C.set_backward_mode("packed")
 
 
-@pytest.mark.parametrize("impl", ["mfma", "valu"])
+@pytest.mark.parametrize("impl", ["mfma", "valu", "mom"])
 def test_parity_alternate_kernels(impl):
     """kernel families are selected per process (HSR_FWD_IMPL / HSR_BWD_IMPL = mfma | valu; defaults: VALU forward,
-    matrix-core backward for K <= 27): run parity cases of the non-default combination in a child process"""
+    matrix-core backward for K <= 27; "mom" = the backward that also forms the six alpha-path moments on the matrix cores):
+    run parity cases of the non-default combination in a child process"""
     import subprocess
     import sys
     code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"

@@ -1,0 +1,13 @@
+# parity cases + headline bench with HSR_BWD_IMPL=$1 (usage: bash tools/try_bwd_impl.sh mom)
+export HSR_BWD_IMPL=$1
+python - <<'PY'
+import sys; sys.path[:0]=['hier-slam_amd','tests']
+import scenes
+from test_gpu_parity import CASES, _compare
+for n in ('replica_tree_k26','scannet_tree_k16','generic_k5_white_bg','plain_mask','huge_splats','deep_tiles_3000','semantic_k0','culled_behind_camera'):
+    W,H,P,K,kind,sm,sem,var,bg,beh = CASES[n]
+    cam,sc,up = scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)
+    _compare(cam,sc,up,sem,var,None); print('ok', n)
+PY
+for i in 1 2; do python bench.py --no-cpu-baseline --steps 50 --warmup 10 > gpurun_out/try_bwd.json && python -c "
+import json;d=json.load(open('gpurun_out/try_bwd.json'));print(round(d['value'],1), {a:round(b,4) for a,b in d['stages_ms'].items()})"; done
