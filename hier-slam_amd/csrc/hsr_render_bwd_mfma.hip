@@ -21,6 +21,22 @@
 #include "hsr_tile_common.h"
 #include "hsr_wave_reduce.h"
 
+#ifdef HSR_TRACE
+// Diagnostic build only (make -C hier-slam_amd/csrc trace -> libhsr_rast_trace.so, tools/trace_bwd.py): per-wave cycle counts of
+// the phases of this kernel, s_memtime deltas accumulated in registers and dumped at the end.  Never compiled into the product.
+#define HSR_TRACE_SLOTS 8
+__device__ unsigned long long g_hsr_trace[16384 * HSR_TRACE_SLOTS];
+extern "C" int hsr_debug_read_trace(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hsr_trace), sizeof(unsigned long long) * (size_t)n);
+}
+#define TR_NOW() clock64()
+#define TR_ADD(acc, t0) (acc) += (unsigned long long)(clock64() - (t0))
+#else
+#define TR_NOW() 0ll
+#define TR_ADD(acc, t0) ((void)0)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -61,6 +77,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
     const float tile_x0 = (float)(tg.tx * HSR_TILE_X), tile_y0 = (float)(tg.ty * HSR_TILE_Y);
     const uint2 range = a.ranges[tile];
     float* panel = s_panel[wv];
+    unsigned long long tr_stage = 0, tr_loop = 0, tr_flush = 0, tr_emit = 0, tr_visits = 0, tr_accepted = 0;
+    const long long tr_t0 = TR_NOW();
+    (void)tr_stage; (void)tr_loop; (void)tr_flush; (void)tr_emit; (void)tr_visits; (void)tr_accepted; (void)tr_t0;
 
     // Every prologue load is unconditional (out-of-image lanes read pixel 0 and are zeroed afterwards) and
     // issued before anything consumes one: a per-lane guard makes hipcc branch around each load and wait for it
@@ -117,6 +136,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
         }
     }
     const int hi_all = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    const long long tr_t1 = TR_NOW();   // end of the prologue
+    (void)tr_t1;
 
     const float bg_dot = a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2;
     const float kx = (0.5f * a.W) / HSR_LOG2E, ky = (0.5f * a.H) / HSR_LOG2E;
@@ -143,11 +164,16 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
     // wave-instruction covering the Gaussian's whole packed row — just before the next group's s-th splat
     // overwrites that panel row.  Atomics are thereby spaced one per accepted splat instead of bursts of 24.
     auto emit_row = [&](int srow) {
+        const long long te = TR_NOW();
+        (void)te;
         const float val = panel[srow * MF_STRIDE + lane];
         if (emit_lane && !(a.debug_flags & 1))
             atomicAdd(a.grow + (size_t)s_prev_id[wv][srow] * a.grow_stride + lane, val);
+        TR_ADD(tr_emit, te);
     };
     auto flush = [&]() {
+        const long long tf = TR_NOW();
+        (void)tf;
         if (a.debug_flags & 2) {  // timing experiment: no MFMA / no flush atomics
             nslot = 0;
             return;
@@ -186,6 +212,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
             if (lane < MF_SLOTS) s_prev_id[wv][lane] = s_slot_id[wv][lane];
             prev_n = nslot;
             nslot = 0;
+            TR_ADD(tr_flush, tf);
             return;
         }
         // legacy arrays: atomic targets of the columns this lane holds, recomputed once per 16 splats
@@ -245,6 +272,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
+        const long long ts = TR_NOW();
+        (void)ts;
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
@@ -258,6 +287,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
         __syncthreads();
         load_record(hi - BATCH);
         load_id(hi - 2 * BATCH);
+        TR_ADD(tr_stage, ts);
+        const long long tl = TR_NOW();
+        (void)tl;
         if (hi - cnt < wmax) {  // else: this wave's pixels all stopped in front of this batch
             for (int seg = 0; seg < 4; seg++) {
                 const int m = s_lcnt[wv][seg];
@@ -280,7 +312,13 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
                     const float G = __builtin_amdgcn_exp2f(power2);
                     const float alpha = fminf(0.99f, co.y * G);
                     const bool active = pos < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+#ifdef HSR_TRACE
+                    tr_visits++;
+#endif
                     if (__ballot(active) == 0ull) continue;
+#ifdef HSR_TRACE
+                    tr_accepted++;
+#endif
 
                     const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
                     const float test_T = T * inv_one_m_a;
@@ -333,6 +371,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
                 }
             }
         }
+        TR_ADD(tr_loop, tl);
     }
     if (packed) {
         for (int sr = nslot; sr < prev_n; sr++) emit_row(sr);  // rows of the previous group not displaced yet
@@ -344,6 +383,17 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
     } else if (nslot > 0) {
         flush();
     }
+#ifdef HSR_TRACE
+    if (lane == 0) {
+        const int wid = tile * 4 + wv;
+        if (wid < 16384) {
+            unsigned long long* o = g_hsr_trace + (size_t)wid * HSR_TRACE_SLOTS;
+            o[0] = (unsigned long long)(clock64() - tr_t0);
+            o[1] = (unsigned long long)(tr_t1 - tr_t0);
+            o[2] = tr_stage; o[3] = tr_loop; o[4] = tr_flush; o[5] = tr_emit; o[6] = tr_visits; o[7] = tr_accepted;
+        }
+    }
+#endif
 }
 
 }  // namespace
