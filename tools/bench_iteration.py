@@ -99,9 +99,34 @@ def measure(P=500000, W=1200, H=680, iters=20):
             iteration(fused, leaf)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters * 1e3
+    def tracking(fused):
+        """scripts/hierslam.py:1683-1860 per iteration: pose gradients only, masked L1 sums on depth and colour"""
+        rv = SH.transformed_params2rendervar_semantic(params, SH.transform_to_frame(params, 1, False, True)) if fused else eager_prep(params, 1)
+        im, radius, sem, depth, med, opac = GaussianRasterizer_semantic(raster_settings=cam)(**rv)
+        mask = ((gt_d > 0) & ~torch.isnan(depth) & (opac > 0.99)).detach()
+        if fused:
+            loss = L.masked_l1(depth, gt_d, mask, "sum") + 0.5 * L.masked_l1(im, gt_im, mask, "sum")
+        else:
+            loss = torch.abs(gt_d - depth)[mask].sum() + 0.5 * torch.abs(gt_im - im)[torch.tile(mask, (3, 1, 1))].sum()
+        loss.backward()
+        return loss
+
+    def time_tracking(fused):
+        for _ in range(3):
+            tracking(fused)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            for v in params.values():
+                v.grad = None
+            tracking(fused)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
     lf, le = float(iteration(True).detach()), float(iteration(False).detach())
     return {"workload": "mapping iteration without optimizer: prep + semantic render + mapping losses + backward, %dx%d, P=%d, K=%d" % (W, H, P, K),
             "fused_ms": timeit(True), "eager_around_same_rasterizer_ms": timeit(False), "loss_fused": lf, "loss_eager": le,
+            "tracking_iteration": {"note": "pose-only iteration (scripts/hierslam.py:1683-1860): prep with camera_grad, render, masked L1 sums, backward",
+                                   "fused_ms": time_tracking(True), "eager_around_same_rasterizer_ms": time_tracking(False)},
             "with_leaf_head": {"note": "mapping iterations >= 14 add the 1x1-conv leaf MLP + cross-entropy (scripts/hierslam.py:975-983)",
                                "fused_ms": timeit(True, True), "eager_around_same_rasterizer_ms": timeit(False, True),
                                "loss_fused": float(iteration(True, True).detach()), "loss_eager": float(iteration(False, True).detach())}}
