@@ -323,11 +323,16 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
                     const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
                     const float test_T = T * inv_one_m_a;
                     const float w = active ? alpha * test_T : 0.f;
+                    // nslot / prev_n are wave-uniform but live in vector registers (they change under divergent-looking
+                    // control flow): pin them to scalars here so that the panel / row addressing runs on the scalar unit —
+                    // the blend loop is VALU-port bound
+                    nslot = __builtin_amdgcn_readfirstlane(nslot);
+                    prev_n = __builtin_amdgcn_readfirstlane(prev_n);
                     // packed mode: the previous group's row parked in this panel row leaves now
                     if (nslot < prev_n) emit_row(nslot);
                     // direct sums go through the panel -> MFMA
                     panel[nslot * MF_STRIDE + lane] = w;
-                    if (lane == 0) s_slot_id[wv][nslot] = s_id[j];
+                    s_slot_id[wv][nslot] = s_id[j];   // every lane stores the same value to the same address: no exec juggling
 
                     const float h = fmaf(cd.x, dpx0, fmaf(cd.y, dpx1, fmaf(cd.z, dpx2, fmaf(cd.w, dpd, dpo))));
                     const float Rn = fmaf(last_alpha, last_h - Rb, Rb);

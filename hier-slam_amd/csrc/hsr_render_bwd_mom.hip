@@ -288,6 +288,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mom_kernel(RenderBwdArgs a)
                     const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
                     const float test_T = T * inv_one_m_a;
                     const float w = active ? alpha * test_T : 0.f;
+                    // wave-uniform counters pinned to scalars: the panel / row addressing then runs on the scalar unit
+                    nslot = __builtin_amdgcn_readfirstlane(nslot);
+                    prev_n = __builtin_amdgcn_readfirstlane(prev_n);
                     // packed mode: the previous group's row parked in this panel row leaves now
                     if (nslot < prev_n) emit_row(nslot);
                     const float h = fmaf(cd.x, dpx0, fmaf(cd.y, dpx1, fmaf(cd.z, dpx2, fmaf(cd.w, dpd, dpo))));
@@ -298,10 +301,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mom_kernel(RenderBwdArgs a)
                     // both weights of the splat go to their panels: w -> D = W.G, q -> the six moments
                     panel[nslot * MF_STRIDE + lane] = w;
                     qpanel[(nslot & (QS - 1)) * MF_STRIDE + lane] = q;
-                    if (lane == 0) {
-                        s_slot_id[wv][nslot] = s_id[j];
-                        s_slot_j[wv][nslot] = j;
-                    }
+                    s_slot_id[wv][nslot] = s_id[j];
+                    s_slot_j[wv][nslot] = j;
                     if (active) {
                         if (test_T > 0.5f && T < 0.5f) med_id = s_id[j];
                         Rb = Rn;

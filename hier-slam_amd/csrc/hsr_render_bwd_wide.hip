@@ -256,10 +256,13 @@ __global__ void __launch_bounds__(256, 2) render_bwd_wide_kernel(RenderBwdArgs a
                     const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
                     const float test_T = T * inv_one_m_a;
                     const float w = active ? alpha * test_T : 0.f;
+                    // wave-uniform counters pinned to scalars: the panel / row addressing then runs on the scalar unit
+                    nslot = __builtin_amdgcn_readfirstlane(nslot);
+                    prev_n = __builtin_amdgcn_readfirstlane(prev_n);
                     // packed mode: the previous group's row parked in this panel row leaves now
                     if (nslot < prev_n) emit_row(nslot);
                     panel[nslot * WF_STRIDE + lane] = w;
-                    if (lane == 0) s_slot_id[wv][nslot] = s_id[j];
+                    s_slot_id[wv][nslot] = s_id[j];
 
                     if (BASE) {
                         const float4 cd = s_col[j];
