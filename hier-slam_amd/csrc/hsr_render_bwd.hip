@@ -266,7 +266,11 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
     const dim3 grid(hsr_tile_grid(tiles)), block(256);
     // default for K <= 27: the matrix-core kernel (hsr_render_bwd_mfma.hip), half the VALU instructions of the
     // all-VALU kernels below, which serve K > 27 and HSR_BWD_IMPL=valu (A/B timing, tests).
-    static const bool use_mfma = !(getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "valu"));
+    // the matrix-core kernels address the packed rows with 32-bit element indices: beyond 2^30 row elements (P > 22 M Gaussians
+    // at K = 26) the all-VALU kernels below, which use 64-bit addressing, take over
+    const bool rows_fit_32bit = !a.grow || (size_t)a.P * (size_t)a.grow_stride < ((size_t)1 << 30);
+    static const bool env_mfma = !(getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "valu"));
+    const bool use_mfma = env_mfma && rows_fit_32bit;
     if (use_mfma && (a.semantic ? a.K : 0) <= 27) {  // one matrix-core launch covers the base sums + K <= 27 channels
         static const bool use_mom = getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "mom");
         if (use_mom && a.grow) hsr_launch_render_backward_mom(a, stream);

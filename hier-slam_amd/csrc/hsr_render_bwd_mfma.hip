@@ -167,8 +167,10 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
         const long long te = TR_NOW();
         (void)te;
         const float val = panel[srow * MF_STRIDE + lane];
+        // 32-bit element index (host guarantees P * grow_stride < 2^30): scalar base + 32-bit vector offset instead of a 64-bit
+        // multiply-add per emission
         if (emit_lane && !(a.debug_flags & 1))
-            atomicAdd(a.grow + (size_t)s_prev_id[wv][srow] * a.grow_stride + lane, val);
+            atomicAdd(a.grow + ((uint32_t)s_prev_id[wv][srow] * (uint32_t)a.grow_stride + (uint32_t)lane), val);
         TR_ADD(tr_emit, te);
     };
     auto flush = [&]() {

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mom_kernel(RenderBwdArgs a)
     auto emit_row = [&](int srow) {
         const float val = panel[srow * MF_STRIDE + lane];
         if (emit_lane && !(a.debug_flags & 1))
-            atomicAdd(a.grow + (size_t)s_prev_id[wv][srow] * a.grow_stride + lane, val);
+            atomicAdd(a.grow + ((uint32_t)s_prev_id[wv][srow] * (uint32_t)a.grow_stride + (uint32_t)lane), val);   // 32-bit index: launcher guards P * stride < 2^30
     };
     auto flush = [&]() {
         flush_moments();   // slots of this group whose moments are still pending

@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256, 2) render_bwd_wide_kernel(RenderBwdArgs a
     auto emit_row = [&](int srow) {
         const float val = panel[srow * WF_STRIDE + lane];
         if (emit_col >= 0 && !(a.debug_flags & 1))
-            atomicAdd(a.grow + (size_t)s_prev_id[wv][srow] * a.grow_stride + emit_col, val);
+            atomicAdd(a.grow + ((uint32_t)s_prev_id[wv][srow] * (uint32_t)a.grow_stride + (uint32_t)emit_col), val);   // 32-bit index: launcher guards P * stride < 2^30
     };
     auto flush = [&]() {
         f32x4 acc[NG];
