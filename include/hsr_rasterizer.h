@@ -111,9 +111,10 @@ int hsr_forward_semantic(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* 
  * dL_dmean2D is [P,3] (z unused), dL_dconic [P,4] (.z unused), dL_dopacity [P], dL_dcolor [P,3],
  * dL_ddepth [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4].
  * All are fully overwritten.
- * scratch: device buffer of hsr_backward_scratch_bytes(P, K, R) bytes, or NULL.  With it the backward uses no
- * global atomics (per-instance rows, then a per-Gaussian sum); without it (or for K > 27) the sums are
- * accumulated with fp32 global atomics like the reference.  Either way last bits are order-dependent. */
+ * scratch: device buffer of hsr_backward_scratch_bytes(P, K, R) bytes, or NULL.  With it (default accumulation mode,
+ * hsr_set_backward_mode) the per-splat sums go by fp32 atomics into ONE packed, 64-byte-aligned row per Gaussian
+ * inside the scratch, which the per-Gaussian kernel unpacks; without it they go straight into the six output arrays
+ * like the reference (more atomic requests).  Either way last bits are order-dependent. */
 int hsr_backward(int P, int D, int M, int R, const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
