@@ -272,8 +272,14 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
     static const bool env_mfma = !(getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "valu"));
     const bool use_mfma = env_mfma && rows_fit_32bit;
     if (use_mfma && (a.semantic ? a.K : 0) <= 27) {  // one matrix-core launch covers the base sums + K <= 27 channels
-        static const bool use_mom = getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "mom");
+        // default: 16-lane groups on 4x4 sub-block masks (hsr_render_bwd_sub.hip, packed rows only), 0.37 ms at the headline
+        // workload; HSR_BWD_IMPL=mfma: all 64 lanes on the quadrant list (hsr_render_bwd_mfma.hip, 0.42 ms; also serves the
+        // legacy accumulation mode); HSR_BWD_IMPL=mom: the opt-in moments variant
+        static const char* impl = getenv("HSR_BWD_IMPL");
+        static const bool use_quad = impl && !strcmp(impl, "mfma");
+        static const bool use_mom = impl && !strcmp(impl, "mom");
         if (use_mom && a.grow) hsr_launch_render_backward_mom(a, stream);
+        else if (!use_quad && a.grow) hsr_launch_render_backward_sub(a, stream);
         else hsr_launch_render_backward_mfma(a, stream);
         return HSR_OK;
     }

@@ -171,6 +171,10 @@ __global__ void __launch_bounds__(256, 4) render_bwd_mfma_kernel(RenderBwdArgs a
         // multiply-add per emission
         if (emit_lane && !(a.debug_flags & 1))
             atomicAdd(a.grow + ((uint32_t)s_prev_id[wv][srow] * (uint32_t)a.grow_stride + (uint32_t)lane), val);
+        if (emit_lane && (a.debug_flags & 8))   // timing experiment: twice the atomic requests (second one to a neighbouring row)
+            atomicAdd(a.grow + ((uint32_t)(s_prev_id[wv][srow] ^ 1) * (uint32_t)a.grow_stride + (uint32_t)lane), val);
+        if (emit_lane && (a.debug_flags & 16))  // three times
+            atomicAdd(a.grow + ((uint32_t)(s_prev_id[wv][srow] ^ 2) * (uint32_t)a.grow_stride + (uint32_t)lane), val);
         TR_ADD(tr_emit, te);
     };
     auto flush = [&]() {

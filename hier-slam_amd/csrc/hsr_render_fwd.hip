@@ -40,23 +40,28 @@ struct FwdCfg {
 // opacity/final_T/n_contrib.  MASK: non-semantic variant, writes mask = sum(alpha*T).
 // ALIGNED: the launch covers whole feature rows of an even K (c0 == 0, KC == K): rows are 8-byte
 // aligned and are fetched as float2.
-template <int KC, bool BASE, bool MASK, bool ALIGNED>
-__global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0)
+// SUB: the 16-lane groups of a wave own 4x4 sub-blocks and walk their own lists (hsr_tile_common.h) instead of the wave's
+// quadrant list.
+template <int KC, bool BASE, bool MASK, bool ALIGNED, bool SUB = false>
+__global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_kernel(RenderFwdArgs a, int c0)
 {
     constexpr int KP = FwdCfg<KC>::KP;
-    constexpr int BATCH = FwdCfg<KC>::BATCH;
+    // SUB: 240 splats per batch keep the 16 lists + records of K = 26 under 40 KB (four workgroups per CU)
+    constexpr int BATCH = SUB ? 240 : FwdCfg<KC>::BATCH;
     __shared__ float4 s_geo[BATCH];   // x, y, A, B   (pre-scaled conic, see hsr_tile_common.h)
     __shared__ float2 s_co[BATCH];    // C, opacity
     __shared__ float4 s_col[BATCH];   // r, g, b, depth
     __shared__ float s_sem[KC > 0 ? BATCH * KP : 4];
-    __shared__ uint8_t s_list[4][256];
+    __shared__ uint8_t s_list[SUB ? 1 : 4][256];
     __shared__ uint8_t s_lcnt[4][4];
+    __shared__ uint8_t s_sublist[SUB ? 16 * HSR_SUB_LSTRIDE : 4];
+    __shared__ uint8_t s_subcnt[4][16];
     __shared__ int s_wdone[4];
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
     if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, wv = t >> 6;
-    const TileGeom tg = tile_geom(tile, a.W, a.H, t);
+    const TileGeom tg = SUB ? tile_geom_sub(tile, a.W, a.H, t) : tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
     const size_t N = (size_t)a.W * a.H;
     const size_t pix_id = (size_t)a.W * tg.py + tg.px;
@@ -128,7 +133,8 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
         const int cnt = min(BATCH, n - start);
         uint32_t qmask = 0u;
         if (t < cnt) {
-            qmask = quadrant_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
+            qmask = SUB ? subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0)
+                        : quadrant_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
             s_geo[t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
             s_co[t] = make_float2((-0.5f * HSR_LOG2E) * p_co.z, p_co.w);
             s_col[t] = make_float4(p_r, p_g, p_b, p_d);
@@ -140,12 +146,66 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderFwdArgs a, int c0
                                          4 * q + 2 < KC ? p_sem[4 * q + 2] : 0.f, 4 * q + 3 < KC ? p_sem[4 * q + 3] : 0.f);
             }
         }
-        publish_quadrant_lists(qmask, t, s_list, s_lcnt);
+        if (SUB) publish_subblock_lists(qmask, t, s_sublist, s_subcnt);
+        else publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
         // next batch's gathers go out now and land while this batch is blended
         load_record(start + BATCH);
         load_id(start + 2 * BATCH);
         if (wave_done) continue;
+
+        if constexpr (SUB) {
+            // four lists per wave, one per 16-lane group; the wave iterates to the longest of them
+            const int lane = t & 63, sb = wv * 4 + (lane >> 4);
+            const int total = flatten_sublist(sb, lane, s_sublist, s_subcnt);
+            const int m = max(max(__builtin_amdgcn_readlane(total, 0), __builtin_amdgcn_readlane(total, 16)),
+                              max(__builtin_amdgcn_readlane(total, 32), __builtin_amdgcn_readlane(total, 48)));
+            const uint8_t* list = s_sublist + sb * HSR_SUB_LSTRIDE;
+            int j_next = total > 0 ? (int)list[0] : 0;   // a group past the end of its list re-reads slot 0 (always staged), weight 0
+            for (int k = 0; k < m; k++) {
+                const int j = j_next;
+                const bool valid = k < total;
+                j_next = (k + 1 < total) ? (int)list[k + 1] : 0;
+                const float4 g = s_geo[j];
+                const float2 co = s_co[j];
+                const float dx = g.x - pfx, dy = g.y - pfy;
+                const float power2 = fmaf(co.x, dy * dy, fmaf(g.w, dx * dy, g.z * (dx * dx)));
+                const float alpha = fminf(0.99f, co.y * __builtin_amdgcn_exp2f(power2));
+                bool contrib = valid && !done && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+                const float test_T = T * (1.0f - alpha);
+                if (contrib && test_T < 0.0001f) {
+                    done = true;
+                    contrib = false;
+                }
+                if (__ballot(contrib) == 0ull) continue;
+                const float w = contrib ? alpha * T : 0.f;
+                const float4 cd = s_col[j];
+                if (BASE) {
+                    C0 = fmaf(cd.x, w, C0);
+                    C1 = fmaf(cd.y, w, C1);
+                    C2 = fmaf(cd.z, w, C2);
+                    Dd = fmaf(cd.w, w, Dd);
+                    if (MASK) Mm += w;
+                    if (contrib && T > 0.5f && test_T < 0.5f) median_D = cd.w;
+                }
+                if (KC > 0) {
+                    const float4* row = reinterpret_cast<const float4*>(&s_sem[j * KP]);
+#pragma unroll
+                    for (int q = 0; q < KP / 4; q++) {
+                        const float4 f = row[q];
+                        if (4 * q + 0 < KC) S[4 * q + 0] = fmaf(f.x, w, S[4 * q + 0]);
+                        if (4 * q + 1 < KC) S[4 * q + 1] = fmaf(f.y, w, S[4 * q + 1]);
+                        if (4 * q + 2 < KC) S[4 * q + 2] = fmaf(f.z, w, S[4 * q + 2]);
+                        if (4 * q + 3 < KC) S[4 * q + 3] = fmaf(f.w, w, S[4 * q + 3]);
+                    }
+                }
+                if (contrib) {
+                    T = test_T;
+                    last_contributor = (uint32_t)(start + j + 1);
+                }
+            }
+            continue;
+        }
 
         // this wave's compacted list: four segments (one per staging wave), slot order preserved
         for (int seg = 0; seg < 4; seg++) {
@@ -221,22 +281,40 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
     const dim3 grid(hsr_tile_grid(tiles)), block(256);
-    // default for K <= 27: the per-lane kernels below.  HSR_FWD_IMPL=mfma selects the pair-pipelined matrix-core kernel
-    // (hsr_render_fwd_pair.hip): parity-tested, but 0.27 vs 0.22 ms at the headline workload — the ~25 VALU instructions
-    // that evaluate alpha per list entry dominate, the matrix cores only take the 15 packed FMAs behind them, and every
-    // list entry (not only contributing ones) has to go through the pair.
-    static const bool use_pair = getenv("HSR_FWD_IMPL") && !strcmp(getenv("HSR_FWD_IMPL"), "mfma");
+    // Default for K <= 28: the per-lane kernel on 4x4 sub-block lists (SUB).  Measured at the headline workload (500k
+    // Gaussians, 1200x680, K = 26): 0.18 ms against 0.22 ms for the same kernel on quadrant lists (HSR_FWD_IMPL=valu, kept
+    // for A/B timing and tests) and 0.27 ms for the pair-pipelined matrix-core kernel (HSR_FWD_IMPL=mfma,
+    // hsr_render_fwd_pair.hip: the ~25 VALU instructions that evaluate alpha per list entry dominate, the matrix cores
+    // only take the 15 packed FMAs behind them, and every list entry has to go through the pair).
+    static const char* impl = getenv("HSR_FWD_IMPL");
+    static const bool use_pair = impl && !strcmp(impl, "mfma");
+    static const bool force_valu = impl && !strcmp(impl, "valu");   // quadrant lists, per-lane accumulators for every K
     if (use_pair && hsr_launch_render_forward_pair(a, stream)) return HSR_OK;
     if (!a.semantic) {
-        render_fwd_kernel<0, true, true, false><<<grid, block, 0, stream>>>(a, 0);
+        if (force_valu) render_fwd_kernel<0, true, true, false, false><<<grid, block, 0, stream>>>(a, 0);
+        else render_fwd_kernel<0, true, true, false, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;
     }
     // wide trees (29 <= K <= 124): matrix-core accumulation (hsr_render_fwd_wide.hip) unless HSR_FWD_IMPL=valu asks for
     // the per-lane accumulators below.  Measured at 500k Gaussians, 1200x680 (tools/kcompare.sh), wide vs per-lane:
     // K=33 0.41/0.59 ms, 60 0.43/0.62, 90 0.62/0.96, 102 0.70/1.16, 124 0.71/1.24 — and K=74 0.61/0.54, the one
     // width whose fused per-lane instantiation (222 registers, 2 waves/SIMD) still wins, so it keeps it.
-    static const bool force_valu = getenv("HSR_FWD_IMPL") && !strcmp(getenv("HSR_FWD_IMPL"), "valu");
     if (!force_valu && a.K != 74 && hsr_launch_render_forward_wide(a, stream)) return HSR_OK;
+    if (!force_valu) {
+        switch (a.K) {
+        case 0: render_fwd_kernel<0, true, false, false, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;
+        case 16: render_fwd_kernel<16, true, false, true, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;   // ScanNet tree
+        case 26: render_fwd_kernel<26, true, false, true, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;   // Replica tree
+        case 74: break;
+        default:
+            if (a.K > 124 || a.K <= 28) {   // 32-channel chunks; the first chunk also produces the base outputs
+                render_fwd_kernel<32, true, false, false, true><<<grid, block, 0, stream>>>(a, 0);
+                for (int c0 = 32; c0 < a.K; c0 += 32) render_fwd_kernel<32, false, false, false, true><<<grid, block, 0, stream>>>(a, c0);
+                return HSR_OK;
+            }
+            break;
+        }
+    }
     switch (a.K) {
     case 0: render_fwd_kernel<0, true, false, false><<<grid, block, 0, stream>>>(a, 0); break;
     case 16: render_fwd_kernel<16, true, false, true><<<grid, block, 0, stream>>>(a, 0); break;   // ScanNet tree

@@ -115,6 +115,102 @@ __device__ __forceinline__ int build_flat_list(int wv, int lane, const uint8_t (
     return total;
 }
 
+// ---- 4x4 sub-block decomposition (hsr_render_fwd_sub.hip) ----
+// Same tile and quadrant ownership as above, but lane l of a wave owns pixel (4*(gq&1) + (l&3), 4*(gq>>1) + ((l>>2)&3)) of
+// the quadrant, gq = l >> 4: every 16-lane group of the wave is one 4x4 SUB-BLOCK, and walks its own compacted list.  A
+// SLAM-sized splat (alpha >= 1/255 inside a radius of 3-4 px) touches 3 quadrant visits x 64 lanes today but only ~4 of
+// the 16 sub-blocks x 16 lanes: the blend loop of a wave runs max-over-its-four-groups iterations, 0.6x of the quadrant
+// list at the headline workload (tools/sim in DESIGN §4).  Sub-block b = 4*wave + gq.
+__device__ __forceinline__ TileGeom tile_geom_sub(int tile, int W, int H, int t)
+{
+    TileGeom g;
+    const int tiles_x = (W + HSR_TILE_X - 1) / HSR_TILE_X;
+    g.tx = tile % tiles_x;
+    g.ty = tile / tiles_x;
+    const int wv = t >> 6, l = t & 63, gq = l >> 4;
+    const int qx = (wv & 1) * 8 + (gq & 1) * 4, qy = (wv >> 1) * 8 + (gq >> 1) * 4;
+    g.px = g.tx * HSR_TILE_X + qx + (l & 3);
+    g.py = g.ty * HSR_TILE_Y + qy + ((l >> 2) & 3);
+    g.inside = g.px < W && g.py < H;
+    g.pfx = (float)g.px;
+    g.pfy = (float)g.py;
+    g.qx0 = (float)(g.tx * HSR_TILE_X + qx);
+    g.qy0 = (float)(g.ty * HSR_TILE_Y + qy);
+    return g;
+}
+
+// 16-bit mask of the tile's sub-blocks (bit 4*wave + gq) the splat's alpha >= 1/255 bounding box touches.
+__device__ __forceinline__ uint32_t subblock_mask(float x, float y, float cx, float cy, float cz, float opacity, float tile_x0,
+                                                  float tile_y0)
+{
+    const float t255 = 255.0f * opacity;
+    if (!(t255 >= 1.0f)) return 0u;
+    const float tau2 = 2.0f * __logf(t255) * 1.001f + 1e-4f;
+    const float det = cx * cz - cy * cy;
+    if (!(det > 0.0f) || !(cx > 0.0f) || !(cz > 0.0f)) return 0xFFFFu;
+    const float inv_det = 1.0f / det;
+    const float hx = sqrtf(tau2 * cz * inv_det) * 1.001f + 0.05f;
+    const float hy = sqrtf(tau2 * cx * inv_det) * 1.001f + 0.05f;
+    const float x0 = x - hx - tile_x0, x1 = x + hx - tile_x0;
+    const float y0 = y - hy - tile_y0, y1 = y + hy - tile_y0;
+    // column c / row r of sub-blocks covers pixel centres [4c, 4c + 3]
+    uint32_t cm = 0u, rm = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        cm |= (uint32_t)(x0 <= 4.0f * c + 3.0f && x1 >= 4.0f * c) << c;
+        rm |= (uint32_t)(y0 <= 4.0f * c + 3.0f && y1 >= 4.0f * c) << c;
+    }
+    // bit of sub-block (column c, row r): wave = (r>>1)*2 + (c>>1), gq = (r&1)*2 + (c&1)  ->  8*(r>>1) + 4*(c>>1) + 2*(r&1) + (c&1)
+    const uint32_t s = (cm & 3u) | ((cm >> 2) << 4);  // columns spread to bits 0, 1, 4, 5
+    uint32_t m = 0u;
+    if (rm & 1u) m |= s;
+    if (rm & 2u) m |= s << 2;
+    if (rm & 4u) m |= s << 8;
+    if (rm & 8u) m |= s << 10;
+    return m;
+}
+
+constexpr int HSR_SUB_LSTRIDE = 260;   // bytes per sub-block list: 256 slots + 4 so that the four groups of a wave hit different banks
+
+// Staging side: s_list[b * LSTRIDE + sw*64 + k] = k-th slot staged by wave sw that touches sub-block b; s_lcnt[sw][b] = how many.
+__device__ __forceinline__ void publish_subblock_lists(uint32_t mask, int t, uint8_t* s_list, uint8_t (*s_lcnt)[16])
+{
+    const int lane = t & 63, sw = t >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        const bool on = (mask >> b) & 1u;
+        const uint64_t m = __ballot(on);
+        if (on) s_list[b * HSR_SUB_LSTRIDE + sw * 64 + __popcll(m & lt)] = (uint8_t)t;
+        if (lane == 0) s_lcnt[sw][b] = (uint8_t)__popcll(m);
+    }
+}
+
+// Consumer side: each 16-lane group closes the gaps between the four segments of its sub-block's list, in place (every copy
+// moves an entry to a lower or equal index, segment by segment in ascending order; only this group reads or writes the list
+// between the two workgroup barriers).  Returns this group's list length.
+__device__ __forceinline__ int flatten_sublist(int sb, int lane, uint8_t* s_list, const uint8_t (*s_lcnt)[16])
+{
+    const int l16 = lane & 15;
+    uint8_t* list = s_list + sb * HSR_SUB_LSTRIDE;
+    int total = s_lcnt[0][sb];
+#pragma unroll
+    for (int seg = 1; seg < 4; seg++) {
+        const int c = s_lcnt[seg][sb];
+        if (total != seg * 64) {
+#pragma unroll
+            for (int i = 0; i < 64; i += 16) {
+                const bool mv = i + l16 < c;
+                const uint8_t v = list[seg * 64 + i + l16];
+                if (mv) list[total + i + l16] = v;
+            }
+        }
+        total += c;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return total;
+}
+
 // ---- packed per-Gaussian gradient row (backward, default accumulation mode) ----
 // The reference keeps the per-Gaussian sums in six separate arrays (dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors,
 // dL_ddepths, dL_dsemantics: rasterize_points.cu:378-388), so one (tile, Gaussian) update touches six cache lines.

@@ -157,9 +157,10 @@ def test_parity_other_accumulation_modes(name, mode):
 
 @pytest.mark.parametrize("impl", ["mfma", "valu", "mom"])
 def test_parity_alternate_kernels(impl):
-    """kernel families are selected per process (HSR_FWD_IMPL / HSR_BWD_IMPL = mfma | valu; defaults: VALU forward,
-    matrix-core backward for K <= 27; "mom" = the backward that also forms the six alpha-path moments on the matrix cores):
-    run parity cases of the non-default combination in a child process"""
+    """kernel families are selected per process (HSR_FWD_IMPL / HSR_BWD_IMPL; defaults for K <= 27: per-lane forward and
+    matrix-core backward on 4x4 sub-block lists).  "mfma" = pair-pipelined matrix-core forward + the quadrant-list matrix-core
+    backward, "valu" = quadrant-list per-lane kernels both ways, "mom" = the backward that also forms the six alpha-path moments
+    on the matrix cores: run parity cases of each non-default combination in a child process"""
     import subprocess
     import sys
     code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
