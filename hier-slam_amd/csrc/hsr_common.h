@@ -40,6 +40,33 @@ struct BinState {
     uint32_t* hist;           // radix-sort per-block digit histograms
 };
 
+// Binning state resolved ON THE DEVICE from num_rendered (speculative forward, hsr_api.hip): the host enqueues the emit,
+// per-tile sort and render kernels before it has read num_rendered back, so their array bases — which depend on it
+// (hsr_carve_bin) — are derived by the kernels themselves from the device-side counter.  base == NULL: not used.
+struct BinDevRef {
+    char* base;               // the caller's binning buffer
+    const uint32_t* R_dev;    // num_rendered, written by the scan
+    size_t capacity;          // bytes usable from base
+};
+constexpr int HSR_SORT_TILE = 4096;   // pairs per radix-sort block (hsr_sort.hip)
+__host__ __device__ inline uint32_t hsr_sort_hist_entries_inline(uint32_t R)
+{
+    const uint32_t nblocks = (R + HSR_SORT_TILE - 1) / HSR_SORT_TILE;
+    return 256u * (nblocks > 0 ? nblocks : 1u) + 256u;
+}
+// same arithmetic as hsr_carve_bin (each array 256-byte aligned); false when the buffer is too small for R instances
+__host__ __device__ inline bool hsr_bin_resolve(const BinDevRef& ref, uint32_t R, BinState* out)
+{
+    const size_t Rn = R > 0 ? R : 1;
+    uintptr_t p = reinterpret_cast<uintptr_t>(ref.base);
+    p = (p + 255) & ~(uintptr_t)255; out->keys_unsorted = reinterpret_cast<uint64_t*>(p); p += 8 * Rn;
+    p = (p + 255) & ~(uintptr_t)255; out->keys = reinterpret_cast<uint64_t*>(p); p += 8 * Rn;
+    p = (p + 255) & ~(uintptr_t)255; out->vals_unsorted = reinterpret_cast<uint32_t*>(p); p += 4 * Rn;
+    p = (p + 255) & ~(uintptr_t)255; out->vals = reinterpret_cast<uint32_t*>(p); p += 4 * Rn;
+    p = (p + 255) & ~(uintptr_t)255; out->hist = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)hsr_sort_hist_entries_inline(R);
+    return p - reinterpret_cast<uintptr_t>(ref.base) <= ref.capacity && R <= 0x7fffffffu;
+}
+
 size_t hsr_carve_geom(char* base, int P, GeomState* out);
 size_t hsr_carve_img(char* base, int W, int H, ImgState* out);
 size_t hsr_carve_bin(char* base, int R, BinState* out);
@@ -96,8 +123,8 @@ bool hsr_bin_plan(int P, int T, size_t scratch_words, HsrBinPlan* plan);   // fa
 int hsr_launch_bin_count(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, uint32_t* scratch,
                          uint2* ranges, hipStream_t stream);               // per-tile counts -> ranges (no num_rendered needed)
 int hsr_launch_bin_emit(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, const uint32_t* scratch,
-                        uint64_t* comp, hipStream_t stream);               // (depth, index) composites into the tile segments
-int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream);  // per-tile (depth, index) sort
+                        uint64_t* comp, hipStream_t stream, const BinDevRef* ref = nullptr);   // (depth, index) composites into the tile segments
+int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream, const BinDevRef* ref = nullptr);  // per-tile (depth, index) sort
 int hsr_sort_tile_passes(int end_bit);
 bool hsr_sort_emit_into_sorted_buffers(int end_bit);
 int hsr_launch_tile_ranges(int R, int T, const uint64_t* keys, uint2* ranges, hipStream_t stream);
@@ -121,6 +148,7 @@ struct RenderFwdArgs {
     float* out_opacity;
     float* out_mask;  // non-semantic variant only
     int debug_flags;  // ablation switches for tools/ablate.sh (wide kernel: 1 no MFMA, 2 no row gather, 4 no blend loop); 0 in production
+    BinDevRef bin;    // base != NULL: point_list is resolved on the device (speculative forward)
 };
 int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream);
 bool hsr_launch_render_forward_pair(const RenderFwdArgs& a, hipStream_t stream);  // non-semantic / K <= 27, pair-pipelined MFMA

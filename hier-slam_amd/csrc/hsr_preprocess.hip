@@ -424,8 +424,13 @@ __global__ void __launch_bounds__(1024) bin_offsets_kernel(int T, const uint32_t
 
 __global__ void __launch_bounds__(BIN_THREADS) bin_emit_kernel(int P, int per_block, const int* __restrict__ radii, int tiles_x, int tiles_y,
                                                        GeomState g, const uint32_t* __restrict__ table, const uint32_t* __restrict__ base,
-                                                       uint64_t* __restrict__ comp)
+                                                       uint64_t* __restrict__ comp, BinDevRef ref)
 {
+    if (ref.base) {   // speculative forward: the array lives where num_rendered says
+        BinState bs;
+        if (!hsr_bin_resolve(ref, *ref.R_dev, &bs)) return;
+        comp = bs.keys;
+    }
     extern __shared__ uint32_t s_cur[];   // [T]
     const int T = tiles_x * tiles_y;
     const uint32_t* row = table + (size_t)blockIdx.x * T;
@@ -510,13 +515,13 @@ int hsr_launch_bin_count(const HsrBinPlan& plan, int P, const int* radii, int ti
 }
 
 int hsr_launch_bin_emit(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, const uint32_t* scratch,
-                        uint64_t* comp, hipStream_t stream)
+                        uint64_t* comp, hipStream_t stream, const BinDevRef* ref)
 {
     const int T = tiles_x * tiles_y;
     const uint32_t* table = scratch;
     const uint32_t* base = table + (size_t)plan.nblk * T + T;
     bin_emit_kernel<<<plan.nblk, BIN_THREADS, (size_t)T * sizeof(uint32_t), stream>>>(P, plan.per_block, radii, tiles_x, tiles_y, g, table,
-                                                                                      base, comp);
+                                                                                      base, comp, ref ? *ref : BinDevRef{nullptr, nullptr, 0});
     return HSR_OK;
 }
 

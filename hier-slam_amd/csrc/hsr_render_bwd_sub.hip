@@ -18,7 +18,7 @@
 //   * the 7 values that are not of the form sum_pixels w*g are reduced over the 16 lanes of the group (four in-row
 //     butterfly stages) into a per-(entry, group) slot and summed over the groups once per chunk;
 //   * the chunk's rows leave with one atomic per accumulator register (4 rows x 64 bytes each) plus two for the butterfly
-//     columns: the same 3 requests per (splat, quadrant) as hsr_render_bwd_mfma.hip.
+//     columns (8 rows x 7 values each): the same 3 requests per (splat, quadrant) as hsr_render_bwd_mfma.hip.
 // Merging further, over the TILE, would cut the atomic requests by a quarter — they execute at the memory side at a
 // fixed rate (MI355X guide, "Global float atomics"; twice the requests = +0.15 ms here) — but the only place the four
 // waves can meet is an LDS table, and ds_add_f32 costs ~170 cycles per wave-instruction on gfx950 (measured with exactly
@@ -182,17 +182,14 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 if (row < nrows && colg[g] >= 0 && acc[g][r] != 0.f && !(a.debug_flags & 1))
                     atomicAdd(a.grow + (base + (uint32_t)colg[g]), acc[g][r]);
         }
-        // butterfly columns: lane -> (row = lane >> 2, values lane & 3 and 4 + (lane & 3)): the four lanes of a row share its line
-        {
-            const int row = lane >> 2, vi = lane & 3;
+        // butterfly columns 0..6: two wave-instructions of 8 rows x 7 values, so that each row's line is ONE request
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
             const float* src = u7 + row * 32 + vi;
-            const float lo = (src[0] + src[8]) + (src[16] + src[24]);
-            const float hi = (src[4] + src[12]) + (src[20] + src[28]);
+            const float val = (src[0] + src[8]) + (src[16] + src[24]);
             const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride + (uint32_t)vi;
-            if (row < nrows && !(a.debug_flags & 1)) {
-                if (lo != 0.f) atomicAdd(a.grow + base, lo);
-                if (vi < 3 && hi != 0.f) atomicAdd(a.grow + (base + 4u), hi);
-            }
+            if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
     };
 

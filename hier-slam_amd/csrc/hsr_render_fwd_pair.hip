@@ -41,6 +41,11 @@ __global__ void __launch_bounds__(256, 4) render_fwd_pair_kernel(RenderFwdArgs a
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
     if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (a.bin.base) {   // speculative forward: the list lives where num_rendered says
+        BinState bs;
+        if (!hsr_bin_resolve(a.bin, *a.bin.R_dev, &bs)) return;
+        a.point_list = bs.vals;
+    }
     const TileGeom tg = tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
     const size_t N = (size_t)a.W * a.H;

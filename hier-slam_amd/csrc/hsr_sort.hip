@@ -23,6 +23,7 @@ namespace {
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096
+static_assert(SORT_TILE == HSR_SORT_TILE, "hsr_common.h sizes the histogram scratch");
 
 __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint64_t* __restrict__ keys, int n, int shift,
                                                                  uint32_t mask, int nblocks, uint32_t* __restrict__ hist)
@@ -151,11 +152,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
 
 }  // namespace
 
-uint32_t hsr_sort_hist_entries(int R)
-{
-    const int nblocks = (R + SORT_TILE - 1) / SORT_TILE;
-    return 256u * (uint32_t)(nblocks > 0 ? nblocks : 1) + 256u;  // per-block counts + 256 digit totals
-}
+uint32_t hsr_sort_hist_entries(int R) { return hsr_sort_hist_entries_inline((uint32_t)(R > 0 ? R : 0)); }
 
 
 // ---- phase 2: per-tile sort by (depth bits, Gaussian index) ----
@@ -248,8 +245,13 @@ __device__ __forceinline__ void ts_block_radix(uint64_t* ka, uint32_t* va, uint6
 
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
                                                         uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
-                                                        uint32_t* __restrict__ vals_alt, int gid_passes, int composite_in)
+                                                        uint32_t* __restrict__ vals_alt, int gid_passes, int composite_in, BinDevRef ref)
 {
+    if (ref.base) {   // speculative forward: the arrays live where num_rendered says
+        BinState bs;
+        if (!hsr_bin_resolve(ref, *ref.R_dev, &bs)) return;
+        keys = bs.keys; vals = bs.vals; keys_alt = bs.keys_unsorted; vals_alt = bs.vals_unsorted;
+    }
     __shared__ uint64_t comp[TS_MAX];
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wcnt[4][256];
@@ -340,16 +342,17 @@ int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, int T, uint2* ranges,
     }
     // (b.keys, b.vals) now hold the instances grouped by tile, in emission order inside each tile
     hsr_launch_tile_ranges_only(R, b.keys, ranges, stream);
-    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, 0, 0);
+    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, 0, 0, BinDevRef{nullptr, nullptr, 0});
     return HSR_OK;
 }
 
 // Per-tile sort alone, for segments in ARBITRARY order holding the 8-byte composites written by direct tile binning
 // (hsr_launch_bin_tiles): tiles above TS_MAX entries radix-sort the Gaussian-index bytes before the depth bytes.
-int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream)
+int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream, const BinDevRef* ref)
 {
     int bits = 0;
     while (bits < 32 && (1ull << bits) < (unsigned long long)(P > 1 ? P : 1)) bits++;
-    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 1);
+    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 1,
+                                            ref ? *ref : BinDevRef{nullptr, nullptr, 0});
     return HSR_OK;
 }

@@ -150,3 +150,25 @@ def test_repeatable_and_saved_state_independent():
     up_only_color = {n: (v if n == "color" else torch.zeros_like(v)) for n, v in up.items()}
     _, g1, _ = run_oracle(cam, sc, up_only_color)
     assert_close("grad means3D (first of two in flight)", l1["means3D"].grad.cpu().numpy(), g1["means3D"])
+
+
+def test_speculative_forward_and_its_fallback_agree_with_the_oracle(monkeypatch):
+    """The forward enqueues emit / per-tile sort / render before it has read num_rendered back, with array bases resolved on the
+    device (BinDevRef); if the caller's binning buffer is too small those kernels return at once and the call grows the buffer and
+    runs them again.  Both ways, and with speculation switched off, the state and outputs must match the oracle bit for bit /
+    to 1e-4 (_compare), and num_rendered must be the same."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    W, H, P, K = 203, 131, 3000, 26
+    cam, sc, up = scenes.build(W, H, P, K, seed=5, kind="slam")
+    key = (torch.device("cuda:0").index, P, W, H)
+    _C._binning_hint.pop(key, None)
+    _compare(cam, sc, up, True, "sr", None)                 # default hint 4P: roomy, speculative path
+    R = _C._binning_hint[key]
+    assert R > 0
+    monkeypatch.setitem(_C._binning_hint, key, 1)           # far too small: fallback path (the call grows the buffer)
+    _compare(cam, sc, up, True, "sr", None)
+    assert _C._binning_hint[key] == R
+    monkeypatch.setitem(_C._binning_hint, key, int(R / 1.25) - 900)   # required bytes just below what R needs
+    _compare(cam, sc, up, True, "sr", None)
+    assert _C._binning_hint[key] == R
