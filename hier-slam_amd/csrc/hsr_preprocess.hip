@@ -372,12 +372,14 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_bl
 
 // workgroup = 64 tiles x 16 row groups: every thread sums its group of rows for one tile (a wave reads 256 contiguous
 // bytes per row), the 16 group sums are scanned through LDS, then the thread writes the exclusive prefixes of its rows
+constexpr int BIN_SCAN_TILES = 16;   // tiles per workgroup of bin_scan_kernel: 64 row groups each -> T/16 workgroups fill the chip
 __global__ void __launch_bounds__(1024) bin_scan_kernel(int T, int nblk, uint32_t* __restrict__ table, uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t s_sum[16][65];
-    const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + tl;
-    const int rows = (nblk + 15) / 16;
+    constexpr int GROUPS = 1024 / BIN_SCAN_TILES;
+    __shared__ uint32_t s_sum[GROUPS][BIN_SCAN_TILES + 1];
+    const int tl = threadIdx.x % BIN_SCAN_TILES, grp = threadIdx.x / BIN_SCAN_TILES;
+    const int i = blockIdx.x * BIN_SCAN_TILES + tl;
+    const int rows = (nblk + GROUPS - 1) / GROUPS;
     const int b0 = grp * rows, b1 = min(nblk, b0 + rows);
     uint32_t sum = 0;
     if (i < T)
@@ -385,8 +387,8 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(int T, int nblk, uint32_
     s_sum[grp][tl] = sum;
     __syncthreads();
     uint32_t run = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
+#pragma unroll 8
+    for (int k = 0; k < GROUPS; k++) {
         const uint32_t v = s_sum[k][tl];
         run += k < grp ? v : 0u;
         tot += v;
@@ -399,7 +401,6 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(int T, int nblk, uint32_
         run += c;
     }
 }
-
 __global__ void __launch_bounds__(1024) bin_offsets_kernel(int T, const uint32_t* __restrict__ totals, uint32_t* __restrict__ base,
                                                            uint2* __restrict__ ranges)
 {
@@ -509,7 +510,7 @@ int hsr_launch_bin_count(const HsrBinPlan& plan, int P, const int* radii, int ti
     uint32_t* totals = table + (size_t)plan.nblk * T;
     uint32_t* base = totals + T;
     bin_hist_kernel<<<plan.nblk, BIN_THREADS, (size_t)T * sizeof(uint32_t), stream>>>(P, plan.per_block, radii, tiles_x, tiles_y, g, table);
-    bin_scan_kernel<<<(T + 63) / 64, 1024, 0, stream>>>(T, plan.nblk, table, totals);
+    bin_scan_kernel<<<(T + BIN_SCAN_TILES - 1) / BIN_SCAN_TILES, 1024, 0, stream>>>(T, plan.nblk, table, totals);
     bin_offsets_kernel<<<1, 1024, 0, stream>>>(T, totals, base, ranges);
     return HSR_OK;
 }

@@ -282,8 +282,14 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
     for (int i = t; i < N; i += 256)
         comp[i] = i < n ? (composite_in ? keys[r0 + i] : (((keys[r0 + i] & 0xFFFFFFFFull) << 32) | (uint64_t)vals[r0 + i])) : ~0ull;
     __syncthreads();
+    // Bitonic network.  Thread t does compare-exchange i = t (+256 m) of a step; for strides j <= 64 the 64 exchanges of a wave
+    // stay inside the wave's own 128 elements, and LDS operations of one wave complete in order, so consecutive steps with
+    // j <= 64 need no workgroup barrier: 7 barriers instead of 45 for a 512-entry tile.
+    bool cross = false;   // the previous step exchanged across waves
     for (int k = 2; k <= N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 128 || cross) __syncthreads();
+            cross = j >= 128;
             for (int i = t; i < N / 2; i += 256) {
                 // i-th compare-exchange of this step: partner indices lo < hi differ in bit j
                 const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
@@ -295,9 +301,9 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
                     comp[hi] = a;
                 }
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
     for (int i = t; i < n; i += 256) {
         const uint64_t c = comp[i];
         keys[r0 + i] = tile_hi | (c >> 32);
