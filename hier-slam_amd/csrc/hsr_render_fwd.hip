@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
 {
     constexpr int KP = FwdCfg<KC>::KP;
     // SUB: 240 splats per batch keep the 16 lists + records of K = 26 under 40 KB (four workgroups per CU)
-    constexpr int BATCH = SUB ? 240 : FwdCfg<KC>::BATCH;
+    constexpr int BATCH = (SUB && KC <= 32) ? 240 : FwdCfg<KC>::BATCH;
     __shared__ float4 s_geo[BATCH];   // x, y, A, B   (pre-scaled conic, see hsr_tile_common.h)
     __shared__ float2 s_co[BATCH];    // C, opacity
     __shared__ float4 s_col[BATCH];   // r, g, b, depth
@@ -303,14 +303,15 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     // wide trees (29 <= K <= 124): matrix-core accumulation (hsr_render_fwd_wide.hip) unless HSR_FWD_IMPL=valu asks for
     // the per-lane accumulators below.  Measured at 500k Gaussians, 1200x680 (tools/kcompare.sh), wide vs per-lane:
     // K=33 0.41/0.59 ms, 60 0.43/0.62, 90 0.62/0.96, 102 0.70/1.16, 124 0.71/1.24 — and K=74 0.61/0.54, the one
-    // width whose fused per-lane instantiation (222 registers, 2 waves/SIMD) still wins, so it keeps it.
+    // width whose fused per-lane instantiation (222 registers, 2 waves/SIMD) still wins, so it keeps it (0.47 ms on
+    // sub-block lists).
     if (!force_valu && a.K != 74 && hsr_launch_render_forward_wide(a, stream)) return HSR_OK;
     if (!force_valu) {
         switch (a.K) {
         case 0: render_fwd_kernel<0, true, false, false, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;
         case 16: render_fwd_kernel<16, true, false, true, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;   // ScanNet tree
         case 26: render_fwd_kernel<26, true, false, true, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;   // Replica tree
-        case 74: break;
+        case 74: render_fwd_kernel<74, true, false, true, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;   // ScanNet large tree
         default:
             if (a.K > 124 || a.K <= 28) {   // 32-channel chunks; the first chunk also produces the base outputs
                 render_fwd_kernel<32, true, false, false, true><<<grid, block, 0, stream>>>(a, 0);
