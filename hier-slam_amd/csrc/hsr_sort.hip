@@ -16,6 +16,9 @@
 //               (64-bit masks, v_cmp + s_and), the rank among them is a popcount of the lower-lane
 //               mask, and per-wave running digit counters live in LDS.  Order (wave, round, lane) =
 //               input order, so the scatter is stable.
+#include <stdlib.h>
+#include <string.h>
+
 #include "hsr_common.h"
 
 namespace {
@@ -261,6 +264,10 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
     // composite_in (direct binning): keys[] holds (depth bits << 32) | index per instance, the tile is the workgroup's
     const uint64_t my_tile_hi = (uint64_t)blockIdx.x << 32;
     if (n <= 0) return;
+    if (composite_in == 2) {   // tiles of at most TW_MAX entries belong to tile_sort_wave_kernel
+        if (n <= 512) return;
+        composite_in = 1;
+    }
     if (n == 1 || n > TS_MAX) {
         if (composite_in) {
             for (int i = t; i < n; i += 256) {
@@ -311,6 +318,103 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
     }
 }
 
+// ---- per-tile sort, one WAVE per tile, for tiles of at most 512 entries (direct binning composites) ----
+// The block-wide network above is LDS-bound: every compare-exchange is two 8-byte reads and up to two writes with 2- to
+// 8-way bank conflicts at small strides, 45 steps for a 512-entry tile.  Here a lane keeps E = 2, 4 or 8 CONSECUTIVE
+// elements in registers (N = 64 E): the steps with stride j < E — more than half of them — are register-only, and a step
+// with j >= E exchanges whole E-element blocks with lane ^ (j / E) through a conflict-free LDS buffer (16-byte accesses,
+// lanes contiguous) and keeps the smaller or the larger element of every pair.  One wave, so no barriers at all; four
+// tiles per 256-thread workgroup.  Tiles above 512 entries are left to tile_sort_kernel (which skips the others).
+constexpr int TW_MAX = 512;   // tile_sort_kernel's composite_in == 2 branch uses the same bound
+
+template <int E>
+__device__ __forceinline__ void wave_bitonic(uint64_t (&x)[E], int lane, ulonglong2* buf)
+{
+    constexpr int N = 64 * E;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+                // both partners in this lane's registers
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    if ((r & j) == 0) {
+                        const bool up = k < E ? ((r & k) == 0) : (((E * lane) & k) == 0);
+                        const uint64_t a = x[r], b = x[r + j];
+                        const bool sw = (a > b) == up;
+                        x[r] = sw ? b : a;
+                        x[r + j] = sw ? a : b;
+                    }
+                }
+            } else {
+                const int m = j / E;   // partner lane = lane ^ m holds the partner of every one of my elements
+#pragma unroll
+                for (int q = 0; q < E / 2; q++) buf[q * 64 + lane] = make_ulonglong2(x[2 * q], x[2 * q + 1]);
+                // the reads below are of OTHER lanes' stores: per thread the addresses provably differ, so without a
+                // wavefront-scope release/acquire pair the compiler is free to hoist them above the stores
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const bool keep_min = ((lane & m) == 0) == (((E * lane) & k) == 0);
+#pragma unroll
+                for (int q = 0; q < E / 2; q++) {
+                    const ulonglong2 y = buf[q * 64 + (lane ^ m)];
+                    const uint64_t a0 = x[2 * q], a1 = x[2 * q + 1];
+                    x[2 * q] = keep_min ? (a0 < y.x ? a0 : y.x) : (a0 > y.x ? a0 : y.x);
+                    x[2 * q + 1] = keep_min ? (a1 < y.y ? a1 : y.y) : (a1 > y.y ? a1 : y.y);
+                }
+                // ... and the next exchange's stores must stay behind these loads
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_tile(int r0, int n, int lane, uint64_t tile_hi, uint64_t* __restrict__ keys,
+                                               uint32_t* __restrict__ vals, ulonglong2* buf)
+{
+    uint64_t x[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int e = E * lane + r;
+        x[r] = e < n ? keys[r0 + e] : ~0ull;
+    }
+    wave_bitonic<E>(x, lane, buf);
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int e = E * lane + r;
+        if (e < n) {
+            keys[r0 + e] = tile_hi | (x[r] >> 32);
+            vals[r0 + e] = (uint32_t)x[r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ vals, BinDevRef ref)
+{
+    __shared__ ulonglong2 s_buf[4][4 * 64];   // per wave: E/2 <= 4 rows of 64 x 16 bytes
+    if (ref.base) {   // speculative forward: the arrays live where num_rendered says
+        BinState bs;
+        if (!hsr_bin_resolve(ref, *ref.R_dev, &bs)) return;
+        keys = bs.keys; vals = bs.vals;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wv;
+    if (tile >= T) return;
+    const uint2 rg = ranges[tile];
+    const int r0 = (int)rg.x, n = (int)(rg.y - rg.x);
+    if (n <= 0 || n > TW_MAX) return;
+    const uint64_t tile_hi = (uint64_t)tile << 32;
+    if (n <= 128) wave_sort_tile<2>(r0, n, lane, tile_hi, keys, vals, s_buf[wv]);
+    else if (n <= 256) wave_sort_tile<4>(r0, n, lane, tile_hi, keys, vals, s_buf[wv]);
+    else wave_sort_tile<8>(r0, n, lane, tile_hi, keys, vals, s_buf[wv]);
+}
+
 // Sorts the R pairs on key bits [0, end_bit) — the contract of the reference's cub::DeviceRadixSort::SortPairs
 // call (rasterizer_impl.cu:307-312) — in two phases: stable LSD passes over the TILE bits only (bits 32..end_bit,
 // at most 8 per pass), then one per-tile sort by depth (tile_sort_kernel).  ranges[] is produced between the two
@@ -358,7 +462,14 @@ int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStre
 {
     int bits = 0;
     while (bits < 32 && (1ull << bits) < (unsigned long long)(P > 1 ? P : 1)) bits++;
-    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 1,
-                                            ref ? *ref : BinDevRef{nullptr, nullptr, 0});
+    const BinDevRef r = ref ? *ref : BinDevRef{nullptr, nullptr, 0};
+    static const bool block_only = getenv("HSR_SORT_IMPL") && !strcmp(getenv("HSR_SORT_IMPL"), "block");
+    if (block_only) {
+        tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 1, r);
+        return HSR_OK;
+    }
+    // tiles of <= 512 entries: one wave each, elements in registers; the rest: the block-wide LDS network / radix
+    tile_sort_wave_kernel<<<(T + 3) / 4, 256, 0, stream>>>(T, ranges, b.keys, b.vals, r);
+    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 2, r);
     return HSR_OK;
 }
