@@ -255,6 +255,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     ra.W = W; ra.H = H; ra.K = in.semantic ? in.K : 0; ra.semantic = in.semantic;
     ra.ranges = im.ranges; ra.point_list = nullptr; ra.means2D = g.means2D; ra.conic_opacity = g.conic_opacity;
     ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb; ra.semantics = in.semantics;
+    ra.rec = g.rec;
     ra.final_T = im.final_T; ra.n_contrib = im.n_contrib;
     ra.out_color = in.out_color; ra.out_semantic = in.out_semantic; ra.out_depth = in.out_depth;
     ra.out_median_depth = in.out_median; ra.out_opacity = in.out_opacity; ra.out_mask = in.out_mask; ra.debug_flags = 0;
@@ -463,6 +464,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         }
         ra.bg = in.background; ra.ranges = im.ranges; ra.point_list = b.vals; ra.means2D = g.means2D;
         ra.conic_opacity = g.conic_opacity; ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb;
+        ra.rec = g.rec;
         ra.final_T = im.final_T; ra.n_contrib = im.n_contrib;
         ra.dL_dpix = in.dL_dpix; ra.dL_dpix_sem = in.dL_dpix_sem; ra.dL_dpix_depth = in.dL_dpix_depth;
         ra.dL_dpix_median = in.dL_dpix_median; ra.dL_dpix_opacity = in.dL_dpix_opacity;
@@ -534,6 +536,7 @@ size_t hsr_carve_geom(char* base, int P, GeomState* out)
     take(p, g.radii, Pn);
     take(p, g.block_sums, (Pn + 255) / 256 + 1);
     take(p, g.counters, 8);
+    take(p, g.rec, Pn * 4);
     if (out) *out = g;
     return (size_t)(p - base);
 }

@@ -26,6 +26,7 @@ struct GeomState {
     int* radii;               // [P]   internal radii when the caller passes NULL
     uint32_t* block_sums;     // [ceil(P/256)+1] per-preprocess-block partial sums, then exclusive offsets
     uint32_t* counters;       // [8]   [0] = num_rendered
+    float4* rec;              // [P,4] packed record the tile kernels gather: {x, y, depth, -} {conic.xyz, opacity} {r, g, b, -} {-}
 };
 struct ImgState {
     uint2* ranges;        // [T]
@@ -138,6 +139,7 @@ struct RenderFwdArgs {
     const float4* conic_opacity;
     const float* depths;
     const float* colors;     // [P,3]
+    const float4* rec;       // packed per-Gaussian record (GeomState::rec): ONE 64-byte line instead of four arrays, or NULL
     const float* semantics;  // [P,K] or NULL
     float* final_T;
     uint32_t* n_contrib;
@@ -164,6 +166,7 @@ struct RenderBwdArgs {
     const float4* conic_opacity;
     const float* depths;
     const float* colors;
+    const float4* rec;    // packed per-Gaussian record (GeomState::rec), or NULL
     const float* final_T;
     const uint32_t* n_contrib;
     const float* dL_dpix;

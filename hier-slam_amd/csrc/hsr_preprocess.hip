@@ -113,8 +113,10 @@ __device__ void sh_to_rgb(int idx, int deg, int max_coeffs, float px, float py, 
 __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessArgs a, GeomState g, int* __restrict__ radii)
 {
     __shared__ uint32_t wsum[4];
+    __shared__ float4 s_rec[3][256];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     uint32_t touched = 0;
+    float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;
     if (idx < a.P) {
         int my_radius_i = 0;
         do {
@@ -189,7 +191,16 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessArgs a, GeomS
             g.depths[idx] = tvz;
             my_radius_i = (int)my_radius;
             g.means2D[idx] = make_float2(pix, piy);
-            g.conic_opacity[idx] = make_float4(conx, cony, conz, a.opacities[idx]);
+            const float op = a.opacities[idx];
+            g.conic_opacity[idx] = make_float4(conx, cony, conz, op);
+            {
+                // the record the tile kernels gather per (tile, Gaussian): one 64-byte line instead of a line in each of
+                // means2D / conic_opacity / depths / colours; staged in LDS and written as one contiguous stream below
+                const float* col = a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : g.rgb + 3 * (size_t)idx;
+                rec0 = make_float4(pix, piy, tvz, 0.f);
+                rec1 = make_float4(conx, cony, conz, op);
+                rec2 = make_float4(col[0], col[1], col[2], 0.f);
+            }
             touched = (y1 - y0) * (x1 - x0);
         } while (0);
         radii[idx] = my_radius_i;
@@ -197,8 +208,19 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessArgs a, GeomS
     }
     const uint32_t ws = wave_sum_u32(touched);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
+    s_rec[0][threadIdx.x] = rec0;
+    s_rec[1][threadIdx.x] = rec1;
+    s_rec[2][threadIdx.x] = rec2;
     __syncthreads();
     if (threadIdx.x == 0) g.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // the block's 256 records (4 x 16 bytes each, the fourth unused) as one contiguous, fully coalesced stream
+    float4* out = g.rec + (size_t)blockIdx.x * 1024;
+    const int nrec = min(256, a.P - blockIdx.x * 256);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int f = threadIdx.x + 256 * k, gi = f >> 2, c = f & 3;
+        if (gi < nrec) out[f] = c < 3 ? s_rec[c][gi] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // block-wide exclusive scan of one value per thread (1024 threads = 16 waves)

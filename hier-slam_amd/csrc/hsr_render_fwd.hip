@@ -101,13 +101,25 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
         const int i = start + t;
         if (t < BATCH && i < n) {
             const size_t id = (size_t)id_next;
-            p_xy = a.means2D[id];
-            p_co = a.conic_opacity[id];
-            p_d = a.depths[id];
-            if (BASE) {
-                p_r = a.colors[3 * id];
-                p_g = a.colors[3 * id + 1];
-                p_b = a.colors[3 * id + 2];
+            if (a.rec) {
+                const float4* rec = a.rec + 4 * id;
+                const float4 r0 = rec[0];
+                p_co = rec[1];
+                p_xy = make_float2(r0.x, r0.y);
+                p_d = r0.z;
+                if (BASE) {
+                    const float4 r2 = rec[2];
+                    p_r = r2.x; p_g = r2.y; p_b = r2.z;
+                }
+            } else {
+                p_xy = a.means2D[id];
+                p_co = a.conic_opacity[id];
+                p_d = a.depths[id];
+                if (BASE) {
+                    p_r = a.colors[3 * id];
+                    p_g = a.colors[3 * id + 1];
+                    p_b = a.colors[3 * id + 2];
+                }
             }
             if (KC > 0) {
                 if (ALIGNED) {
