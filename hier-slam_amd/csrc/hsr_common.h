@@ -188,6 +188,7 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream);
 int hsr_launch_render_backward_mfma(const RenderBwdArgs& a, hipStream_t stream);
 int hsr_launch_render_backward_mom(const RenderBwdArgs& a, hipStream_t stream);   // K <= 27, packed mode: all sums on MFMA
 int hsr_launch_render_backward_sub(const RenderBwdArgs& a, hipStream_t stream);   // K <= 27, packed mode: 4x4 sub-block lists, rows merged per tile in LDS
+int hsr_launch_render_backward_subw(const RenderBwdArgs& a, hipStream_t stream);  // K > 27, packed mode: sub-block masks, channel passes
 int hsr_launch_render_backward_wide(const RenderBwdArgs& a, hipStream_t stream);  // semantic, K > 27: matrix-core channel passes
 int hsr_launch_render_backward_rows(const RenderBwdArgs& a, hipStream_t stream);  // returns the kernel's KC
 int hsr_rows_row_floats(int K);

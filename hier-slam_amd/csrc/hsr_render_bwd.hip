@@ -283,8 +283,11 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
         else hsr_launch_render_backward_mfma(a, stream);
         return HSR_OK;
     }
-    if (use_mfma && a.semantic && a.K > 27) {  // wide trees: matrix-core passes of <= 64 channels (hsr_render_bwd_wide.hip)
-        hsr_launch_render_backward_wide(a, stream);
+    if (use_mfma && a.semantic && a.K > 27) {  // wide trees: matrix-core passes of <= 64 channels
+        // default: sub-block masks (hsr_render_bwd_sub.hip, packed rows); HSR_BWD_IMPL=mfma: quadrant lists (hsr_render_bwd_wide.hip)
+        static const bool use_quad_w = getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "mfma");
+        if (a.grow && !use_quad_w) hsr_launch_render_backward_subw(a, stream);
+        else hsr_launch_render_backward_wide(a, stream);
         return HSR_OK;
     }
     if (!a.semantic || a.K == 0) {

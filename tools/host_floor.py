@@ -31,3 +31,11 @@ for rep in range(3):
     for _ in range(200): step()
     torch.cuda.synchronize()
     print("host floor: %.3f ms per fwd+bwd render" % ((time.perf_counter() - t0) / 200 * 1e3))
+if os.environ.get("HSR_HOST_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(300): step()
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
