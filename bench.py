@@ -191,9 +191,11 @@ def main():
         _C._lib.hsr_profile_read(C.byref(prof_all), 1)
         dom_stage = max(range(9), key=lambda i: prof_all.ms[i])
         _C._lib.hsr_profile_select(1 << dom_stage)
+    _C._lib.hsr_profile_host_wait_ms(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_wait_ms = float(_C._lib.hsr_profile_host_wait_ms(1)) / args.steps
     sync()
     t1 = time.perf_counter()
     if not args.no_profile:
@@ -254,6 +256,10 @@ def main():
             out["whole_render"] = {"alg_bytes": tot_alg, "GBps": tot_alg / (ms_per_step * 1e-3) / 1e9,
                                    "frac_of_hbm_peak": tot_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "device_ms_sum": round(sum(v["ms"] for v in stages.values()), 4)}
+        # how long the host sat blocked on the device per step (the forward's num_rendered read-back): about one device step =
+        # device-bound; near zero while ms_per_step exceeds the device time = this box's host cannot keep the device fed
+        out["host"] = {"blocked_on_device_ms_per_step": round(host_wait_ms, 4),
+                       "note": "ms_per_step - blocked = host-side work per step (Python glue + launches)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sc, cam_cpu, up)
         print(json.dumps(out))

@@ -9,6 +9,8 @@
 // backward.  The library holds no state between calls; the reference's per-call cudaMalloc/cudaFree
 // scratch in backward_semantic (rasterizer_impl.cu:673-701) has no counterpart.
 #include <stdarg.h>
+
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -136,9 +138,12 @@ int read_counter_begin(const uint32_t* dev, hipStream_t stream)
     HSR_HIP_CHECK(hipEventRecord(g_counter_event, stream));
     return HSR_OK;
 }
+thread_local double g_host_wait_ms = 0.0;
 int read_counter_end(uint32_t* host_out)
 {
+    const auto t0 = std::chrono::steady_clock::now();
     HSR_HIP_CHECK(hipEventSynchronize(g_counter_event));
+    g_host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *host_out = g_pinned[0];
     return HSR_OK;
 }
@@ -401,7 +406,9 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         hsr_set_error("an upstream-gradient pointer is NULL");
         return HSR_ERR_INVALID_ARGUMENT;
     }
-    if (!in.dL_dmean2D || !in.dL_dconic || !in.dL_dopacity || !in.dL_dcolor || !in.dL_ddepth || !in.dL_dmean3D || !in.dL_dcov3D) {
+    // dL_dconic, dL_ddepth (intermediates the reference keeps to itself, rasterize_points.cu:380-383) and dL_dcov3D may be
+    // NULL = not wanted, as long as a scratch buffer carries the accumulation (checked below for the legacy mode)
+    if (!in.dL_dmean2D || !in.dL_dopacity || !in.dL_dcolor || !in.dL_dmean3D) {
         hsr_set_error("a gradient output pointer is NULL");
         return HSR_ERR_INVALID_ARGUMENT;
     }
@@ -433,6 +440,10 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     const int gstride = hsr_grow_stride(K);
     const bool use_packed = !use_rows && backward_mode() != 2 && in.scratch &&
                             in.scratch_bytes >= (size_t)P * gstride * sizeof(float) + 256;
+    if (!use_rows && !use_packed && (!in.dL_dconic || !in.dL_ddepth)) {
+        hsr_set_error("dL_dconic and dL_ddepth may only be NULL when a scratch buffer carries the accumulation (packed / rows mode)");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
     float* grow = nullptr;
     int rows_kc = 0;
     float* rows = nullptr;
@@ -589,6 +600,13 @@ int hsr_set_backward_mode(int mode)
     }
     g_bwd_mode = mode;
     return HSR_OK;
+}
+
+double hsr_profile_host_wait_ms(int reset)
+{
+    const double v = g_host_wait_ms;
+    if (reset) g_host_wait_ms = 0.0;
+    return v;
 }
 
 int hsr_profile_select(unsigned stage_mask)

@@ -146,10 +146,10 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
         g_m2x = racc[0]; g_m2y = racc[1]; g_cx = racc[2]; g_cy = racc[3]; g_cw = racc[4];
         g_depth = racc[6] + racc[8 + KCC + 3];
         a.out_mean2D[3 * idx] = g_m2x; a.out_mean2D[3 * idx + 1] = g_m2y; a.out_mean2D[3 * idx + 2] = 0.f;
-        reinterpret_cast<float4*>(a.out_conic)[idx] = make_float4(g_cx, g_cy, 0.f, g_cw);
+        if (a.out_conic) reinterpret_cast<float4*>(a.out_conic)[idx] = make_float4(g_cx, g_cy, 0.f, g_cw);
         a.out_opacity[idx] = racc[5] + racc[8 + KCC + 4];
         a.out_color[3 * idx] = racc[8 + KCC]; a.out_color[3 * idx + 1] = racc[8 + KCC + 1]; a.out_color[3 * idx + 2] = racc[8 + KCC + 2];
-        a.out_depth[idx] = g_depth;
+        if (a.out_depth) a.out_depth[idx] = g_depth;
 #pragma unroll
         for (int c = 0; c < KCC; c++)
             if (c < a.K) a.out_semantics[(size_t)idx * a.K + c] = racc[8 + c];
@@ -162,10 +162,10 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
         g_m2x = r0.x; g_m2y = r0.y; g_cx = r0.z; g_cy = r0.w; g_cw = r1.x;
         g_depth = r1.z + d_dep;
         a.out_mean2D[3 * idx] = g_m2x; a.out_mean2D[3 * idx + 1] = g_m2y; a.out_mean2D[3 * idx + 2] = 0.f;
-        reinterpret_cast<float4*>(a.out_conic)[idx] = make_float4(g_cx, g_cy, 0.f, g_cw);
+        if (a.out_conic) reinterpret_cast<float4*>(a.out_conic)[idx] = make_float4(g_cx, g_cy, 0.f, g_cw);
         a.out_opacity[idx] = r1.y + d_op;
         a.out_color[3 * idx] = d_r; a.out_color[3 * idx + 1] = d_g; a.out_color[3 * idx + 2] = d_b;
-        a.out_depth[idx] = g_depth;
+        if (a.out_depth) a.out_depth[idx] = g_depth;
     } else {
         g_m2x = a.dL_dmean2D[3 * idx]; g_m2y = a.dL_dmean2D[3 * idx + 1];
         g_cx = a.dL_dconic[4 * idx]; g_cy = a.dL_dconic[4 * idx + 1]; g_cw = a.dL_dconic[4 * idx + 3];
@@ -302,8 +302,10 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
     a.dL_dmean3D[3 * idx] = gmx;
     a.dL_dmean3D[3 * idx + 1] = gmy;
     a.dL_dmean3D[3 * idx + 2] = gmz;
+    if (a.dL_dcov3D) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    }
     if (a.dL_dscale) {
         a.dL_dscale[3 * idx] = dsc[0];
         a.dL_dscale[3 * idx + 1] = dsc[1];

@@ -77,6 +77,8 @@ def _load():
     lib.hsr_stage_name.argtypes = [ci]
     lib.hsr_profile_enable.restype = ci
     lib.hsr_profile_enable.argtypes = [ci]
+    lib.hsr_profile_host_wait_ms.restype = C.c_double
+    lib.hsr_profile_host_wait_ms.argtypes = [ci]
     lib.hsr_profile_select.restype = ci
     lib.hsr_profile_select.argtypes = [C.c_uint]
     lib.hsr_profile_read.restype = ci
@@ -229,6 +231,11 @@ def rasterize_gaussians_semantic(background, means3D, colors, semantics, opacity
     return r, color, sem, depth, median, opac, radii, g, b, i
 
 
+# Cleared by the autograd node for one call when cov3D_precomp needs no gradient (the usual case: Hier-SLAM passes scales and
+# rotations): dL_dcov3D is then neither allocated nor written, and the backward entry points return None in its place.
+want_cov3D_grad = True
+
+
 def _backward_common(semantic, background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic,
                      dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
@@ -245,10 +252,14 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
     dL_dmeans2D = new((P, 3), **fopt)
     dL_dcolors = new((P, NUM_CHANNELS), **fopt)
     dL_dsemantics = new((P, K), **fopt)
-    dL_ddepths = new((P, 1), **fopt)
-    dL_dconic = new((P, 2, 2), **fopt)
+    # with a scratch buffer (every mode but 'legacy') dL_dconic and dL_ddepths are intermediates nobody reads (the reference
+    # keeps them inside RasterizeGaussiansBackwardCUDA, rasterize_points.cu:380-383): not allocated, not written;
+    # dL_dcov3D only when the caller wants it (want_cov3D_grad, cleared by the autograd node when cov3D_precomp needs no grad)
+    packed_scratch = P != 0 and int(_lib.hsr_backward_scratch_bytes(P, K, int(R))) > 0
+    dL_dconic = None if packed_scratch else new((P, 2, 2), **fopt)
+    dL_ddepths = None if packed_scratch else new((P, 1), **fopt)
     dL_dopacity = new((P, 1), **fopt)
-    dL_dcov3D = new((P, 6), **fopt)
+    dL_dcov3D = new((P, 6), **fopt) if (want_cov3D_grad or P == 0) else None
     dL_dsh = new((P, M, 3), **fopt)
     dL_dscales = new((P, 3), **fopt)
     dL_drotations = new((P, 4), **fopt)

@@ -101,6 +101,14 @@ class _Rasterize(torch.autograd.Function):
         head = (rs.bg, means3D, radii, colors_precomp)
         mid = (scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
                grad_color)
+        _C.want_cov3D_grad = bool(ctx.needs_input_grad[9])   # cov3Ds_precomp
+        try:
+            return _Rasterize._run_backward(ctx, rs, head, mid, tail, semantics_precomp, grad_sem, grad_depth, grad_median, grad_opacity)
+        finally:
+            _C.want_cov3D_grad = True
+
+    @staticmethod
+    def _run_backward(ctx, rs, head, mid, tail, semantics_precomp, grad_sem, grad_depth, grad_median, grad_opacity):
         if ctx.semantic:
             args = head + (semantics_precomp,) + mid + (grad_sem, grad_depth, grad_median, grad_opacity) + tail
             (g_means2D, g_colors, g_sem, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot) = _call(

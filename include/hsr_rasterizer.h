@@ -110,6 +110,8 @@ int hsr_forward_semantic(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* 
  * R = num_rendered returned by the matching hsr_forward; the three buffers are the ones it filled.
  * dL_dmean2D is [P,3] (z unused), dL_dconic [P,4] (.z unused), dL_dopacity [P], dL_dcolor [P,3],
  * dL_ddepth [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4].
+ * dL_dcov3D may be NULL (not wanted); dL_dconic and dL_ddepth — intermediates the reference keeps to itself
+ * (rasterize_points.cu:380-383) — may be NULL when `scratch` carries the accumulation (the default).
  * All are fully overwritten.
  * scratch: device buffer of hsr_backward_scratch_bytes(P, K, R) bytes, or NULL.  With it (default accumulation mode,
  * hsr_set_backward_mode) the per-splat sums go by fp32 atomics into ONE packed, 64-byte-aligned row per Gaussian
@@ -175,6 +177,10 @@ int hsr_profile_enable(int on);
 int hsr_profile_select(unsigned stage_mask);
 int hsr_profile_read(hsr_profile* out, int reset);
 const char* hsr_stage_name(int stage);
+/* milliseconds the calling thread's hsr_forward* calls have spent blocked on the num_rendered read-back since the last reset.
+ * Near zero while the device keeps working = the HOST is the bottleneck of the call sequence (the device idles between
+ * calls); about one device step per call = device-bound. */
+double hsr_profile_host_wait_ms(int reset);
 
 #ifdef __cplusplus
 }
