@@ -90,10 +90,62 @@ def _load():
 
 _lib = _load()
 
+# The same glue as a compiled extension (csrc/hsr_torch_ext.cpp, built by csrc/build_torch_ext.py): used for the four
+# rasterize entry points when present, because the interpreter work per call matters at 0.65 ms per render.  HSR_GLUE=ctypes
+# forces the pure-Python path below (identical behaviour; tests run both).
+_ext = None
+if os.environ.get("HSR_GLUE", "") != "ctypes":
+    try:
+        from . import _hsr_torch as _ext  # noqa: F401
+    except ImportError:
+        _ext = None
+
 # last num_rendered seen per (device, P, W, H): sizes the binning buffer up front so that the steady
 # state needs no grow callback (the reference resizes through a callback every call,
 # rasterize_points.cu:27-33)
-_binning_hint = {}
+class _HintMap(dict):
+    """(device index, P, W, H) -> last num_rendered.  Lives in the extension when that is loaded."""
+
+    def _e(self, key, v):
+        return _ext.binning_hint(int(key[0]), int(key[1]), int(key[2]), int(key[3]), int(v))
+
+    def __getitem__(self, key):
+        if _ext is None:
+            return dict.__getitem__(self, key)
+        v = self._e(key, -1)
+        if v < 0:
+            raise KeyError(key)
+        return v
+
+    def __setitem__(self, key, v):
+        if _ext is None:
+            dict.__setitem__(self, key, v)
+        else:
+            self._e(key, v)
+
+    def __delitem__(self, key):
+        if _ext is None:
+            dict.__delitem__(self, key)
+        else:
+            self._e(key, -2)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) if _ext is None else self._e(key, -1) >= 0
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def pop(self, key, *default):
+        if key in self:
+            v = self[key]
+            del self[key]
+            return v
+        if default:
+            return default[0]
+        raise KeyError(key)
+
+
+_binning_hint = _HintMap()
 
 def set_backward_mode(mode):
     """'packed' (default), 'rows' (experimental, no global atomics) or 'legacy' (reference-style arrays)."""
@@ -154,6 +206,11 @@ class _Grower:
 def _forward_common(semantic, background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
                     campos, prefiltered, debug):
+    if _ext is not None and means3D.is_cuda:
+        return _ext.forward_common(bool(semantic), background, means3D, colors, semantics, opacity, scales, rotations,
+                                   float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
+                                   int(image_height), int(image_width), sh, int(degree), campos, bool(prefiltered), bool(debug),
+                                   torch.cuda.current_stream(means3D.device).cuda_stream)
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:60-62
     _require_gpu(means3D)
@@ -240,6 +297,12 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic,
                      dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
                      binningBuffer, imageBuffer, debug):
+    if _ext is not None and means3D.is_cuda:
+        return _ext.backward_common(bool(semantic), background, means3D, radii, colors, semantics, scales, rotations,
+                                    float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
+                                    dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity,
+                                    sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug),
+                                    bool(want_cov3D_grad), torch.cuda.current_stream(means3D.device).cuda_stream)
     _require_gpu(means3D)
     dev = means3D.device
     P = int(means3D.size(0))

@@ -172,3 +172,23 @@ def test_parity_alternate_kernels(impl):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_ctypes_glue_matches_too():
+    """The four rasterize entry points run through the compiled torch glue (diff_gaussian_rasterization._hsr_torch) when it is
+    built; HSR_GLUE=ctypes selects the pure-Python glue over the same C ABI.  Parity cases through that one, in a child process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
+            "from diff_gaussian_rasterization import _C; assert _C._ext is None;"
+            "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
+            "for n in ('replica_tree_k26','plain_mask','huge_splats','large_tree_k74')];print('ok')")
+    env = dict(os.environ, HSR_GLUE="ctypes")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_compiled_glue_is_loaded():
+    from diff_gaussian_rasterization import _C
+    assert _C._ext is not None, "diff_gaussian_rasterization._hsr_torch is not built (python hier-slam_amd/csrc/build_torch_ext.py)"

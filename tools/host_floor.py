@@ -39,3 +39,18 @@ if os.environ.get("HSR_HOST_PROFILE"):
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+if os.environ.get("HSR_HOST_CALLS"):
+    # time spent inside the two C ABI calls (ctypes glue: run with HSR_GLUE=ctypes)
+    from diff_gaussian_rasterization import _C
+    acc = {"fwd": 0.0, "bwd": 0.0}
+    f0, b0 = _C._lib.hsr_forward_semantic, _C._lib.hsr_backward_semantic
+    def fw(*a):
+        t = time.perf_counter(); r = f0(*a); acc["fwd"] += time.perf_counter() - t; return r
+    def bw(*a):
+        t = time.perf_counter(); r = b0(*a); acc["bwd"] += time.perf_counter() - t; return r
+    _C._lib.hsr_forward_semantic, _C._lib.hsr_backward_semantic = fw, bw
+    t0 = time.perf_counter()
+    for _ in range(300): step()
+    torch.cuda.synchronize()
+    tot = (time.perf_counter() - t0) / 300 * 1e3
+    print("per step %.3f ms: inside hsr_forward_semantic %.3f ms, inside hsr_backward_semantic %.3f ms" % (tot, acc["fwd"] / 300 * 1e3, acc["bwd"] / 300 * 1e3))
