@@ -233,20 +233,13 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
         hsr_launch_preprocess(pa, g, stream);
     }
     HSR_LAUNCH_CHECK(in.debug, stream);
-    {
-        StageTimer tm(HSR_STAGE_FWD_SCAN, stream);
-        hsr_launch_scan_block_sums(P, g, stream);
-    }
-    HSR_LAUNCH_CHECK(in.debug, stream);
-
-    if ((rc = read_counter_begin(g.counters, stream)) != HSR_OK) return rc;
-
     const int end_bit = 32 + (int)higher_msb((uint32_t)T);  // rasterizer_impl.cu:304-312
     // Default: count per tile, emit every instance straight into its tile's segment, then order each segment by
     // (depth, index) in LDS.  HSR_SORT_IMPL=radix or more than 8192 tiles take the emission-order + stable tile-bit
     // radix passes instead; both give the same sorted keys, values and ranges.  The count phase needs neither
-    // num_rendered nor the binning buffer, so it is enqueued BEFORE the host waits for num_rendered: the GPU works
-    // through it while the host wakes up (the reference idles the stream at this point, rasterizer_impl.cu:285).
+    // num_rendered nor the binning buffer — it PRODUCES num_rendered (the scan over the per-block sums rides along in
+    // bin_hist_kernel) — so it is enqueued before the host waits for anything (the reference idles the stream at this
+    // point, rasterizer_impl.cu:285).
     static const bool force_radix = getenv("HSR_SORT_IMPL") && !strcmp(getenv("HSR_SORT_IMPL"), "radix");
     HsrBinPlan plan{0, 0};
     uint32_t* bin_scratch = reinterpret_cast<uint32_t*>(im.final_T);   // free until the render kernel writes it
@@ -254,7 +247,13 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     if (binned) {
         StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
         hsr_launch_bin_count(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, stream);
+    } else {
+        StageTimer tm(HSR_STAGE_FWD_SCAN, stream);
+        hsr_launch_scan_block_sums(P, g, stream);
     }
+    HSR_LAUNCH_CHECK(in.debug, stream);
+
+    if ((rc = read_counter_begin(g.counters, stream)) != HSR_OK) return rc;
 
     RenderFwdArgs ra;
     ra.W = W; ra.H = H; ra.K = in.semantic ? in.K : 0; ra.semantic = in.semantic;

@@ -355,11 +355,24 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_bl
 {
     extern __shared__ uint32_t s_cnt[];   // [T]
     __shared__ uint32_t s_wsum[BIN_THREADS / 64];
+    __shared__ uint32_t s_red[BIN_THREADS / 64];
     const int T = tiles_x * tiles_y;
     for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cnt[i] = 0u;
-    __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g0 = blockIdx.x * per_block;   // per_block is a multiple of 1024: chunks coincide with 4 preprocess blocks
+    // The scan over the preprocess blocks' tile-count sums rides along here (no separate single-workgroup launch): this
+    // workgroup sums the RAW per-block sums in front of its first Gaussian itself — at most P/256 L2-resident words — and the
+    // last workgroup, whose running sum ends at the total, publishes num_rendered.
+    const int nblk_pre = (P + 255) >> 8, pre0 = g0 >> 8;
+    uint32_t part = 0u;
+    for (int j = threadIdx.x; j < pre0 && j < nblk_pre; j += BIN_THREADS) part += g.block_sums[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) s_red[w] = part;
+    __syncthreads();
+    uint32_t chunk_base = 0u;   // sum of the tile counts of every Gaussian in front of the current chunk
+#pragma unroll
+    for (int k = 0; k < BIN_THREADS / 64; k++) chunk_base += s_red[k];
     for (int c = 0; c < per_block && g0 + c < P; c += BIN_THREADS) {
         const int idx = g0 + c + threadIdx.x;
         const uint32_t touched = idx < P ? g.tiles_touched[idx] : 0u;
@@ -373,7 +386,17 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_bl
         __syncthreads();
         if (lane == 63) s_wsum[w] = inc;
         __syncthreads();
-        uint32_t off = g.block_sums[idx < P ? idx >> 8 : 0];
+        // the four preprocess blocks of this chunk: their raw sums give the offsets of blocks 1..3 and the next chunk's base
+        const int pb0 = (g0 + c) >> 8;
+        uint32_t bs[BIN_THREADS / 256];
+#pragma unroll
+        for (int q = 0; q < BIN_THREADS / 256; q++) bs[q] = pb0 + q < nblk_pre ? g.block_sums[pb0 + q] : 0u;
+        uint32_t off = chunk_base;
+#pragma unroll
+        for (int q = 0; q < BIN_THREADS / 256; q++) {
+            off += q < (w >> 2) ? bs[q] : 0u;
+            chunk_base += bs[q];
+        }
         for (int k = w & ~3; k < w; k++) off += s_wsum[k];
         if (idx < P) {
             g.point_offsets[idx] = off + inc;
@@ -387,13 +410,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_bl
             }
         }
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g.counters[0] = chunk_base;   // num_rendered
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * T;
     for (int i = threadIdx.x; i < T; i += BIN_THREADS) row[i] = s_cnt[i];
 }
-
-// workgroup = 64 tiles x 16 row groups: every thread sums its group of rows for one tile (a wave reads 256 contiguous
-// bytes per row), the 16 group sums are scanned through LDS, then the thread writes the exclusive prefixes of its rows
 constexpr int BIN_SCAN_TILES = 16;   // tiles per workgroup of bin_scan_kernel: 64 row groups each -> T/16 workgroups fill the chip
 __global__ void __launch_bounds__(1024) bin_scan_kernel(int T, int nblk, uint32_t* __restrict__ table, uint32_t* __restrict__ totals)
 {
