@@ -139,6 +139,7 @@ int read_counter_begin(const uint32_t* dev, hipStream_t stream)
     return HSR_OK;
 }
 thread_local double g_host_wait_ms = 0.0;
+thread_local int g_last_per_tile = 0;   // num_rendered / tiles of this thread's previous forward: picks the per-tile sort's launch shape
 int read_counter_end(uint32_t* host_out)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -286,7 +287,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
         }
         {
             StageTimer tm(HSR_STAGE_FWD_SORT, stream);
-            hsr_launch_tile_sort(none, T, P, im.ranges, stream, &ref);
+            hsr_launch_tile_sort(none, T, P, im.ranges, stream, &ref, g_last_per_tile);
         }
         ra.bin = ref;
         {
@@ -307,6 +308,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     if (speculated) {
         BinState chk;
         const BinDevRef ref{static_cast<char*>(binning->ptr), nullptr, binning->capacity};
+        g_last_per_tile = R / (T > 0 ? T : 1);
         if (hsr_bin_resolve(ref, R32, &chk)) return R;   // the kernels found the same layout: done
         // too small after all: the speculative kernels returned at once; the render kernel's final_T (= the count table)
         // was not touched either, but recount anyway to keep this rare path independent of that
@@ -326,7 +328,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     if (binned) {
         HSR_LAUNCH_CHECK(in.debug, stream);
         StageTimer tm(HSR_STAGE_FWD_SORT, stream);
-        if (R > 0) hsr_launch_tile_sort(b, T, P, im.ranges, stream);
+        if (R > 0) hsr_launch_tile_sort(b, T, P, im.ranges, stream, nullptr, R / (T > 0 ? T : 1));
     } else {
         // emit into the buffer pair from which the sort's ping-pong passes end in (keys, vals)
         const bool emit_sorted = hsr_sort_emit_into_sorted_buffers(end_bit);

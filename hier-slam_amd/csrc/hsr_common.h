@@ -125,7 +125,8 @@ int hsr_launch_bin_count(const HsrBinPlan& plan, int P, const int* radii, int ti
                          uint2* ranges, hipStream_t stream);               // per-tile counts -> ranges (no num_rendered needed)
 int hsr_launch_bin_emit(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, const uint32_t* scratch,
                         uint64_t* comp, hipStream_t stream, const BinDevRef* ref = nullptr);   // (depth, index) composites into the tile segments
-int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream, const BinDevRef* ref = nullptr);  // per-tile (depth, index) sort
+int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream, const BinDevRef* ref = nullptr,
+                         int avg_per_tile_hint = 0);  // per-tile (depth, index) sort; hint: entries per tile of the previous frame
 int hsr_sort_tile_passes(int end_bit);
 bool hsr_sort_emit_into_sorted_buffers(int end_bit);
 int hsr_launch_tile_ranges(int R, int T, const uint64_t* keys, uint2* ranges, hipStream_t stream);

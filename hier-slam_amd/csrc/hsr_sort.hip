@@ -246,28 +246,18 @@ __device__ __forceinline__ void ts_block_radix(uint64_t* ka, uint32_t* va, uint6
     }
 }
 
-__global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
-                                                        uint32_t* __restrict__ vals_alt, int gid_passes, int composite_in, BinDevRef ref)
+// One tile, the whole workgroup (256 threads).  comp / hist / wcnt: the workgroup's LDS scratch.
+__device__ __forceinline__ void block_sort_tile(int tile, const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
+                                                uint32_t* __restrict__ vals_alt, int gid_passes, int composite_in, uint64_t* comp,
+                                                uint32_t* hist, uint32_t (*wcnt)[256])
 {
-    if (ref.base) {   // speculative forward: the arrays live where num_rendered says
-        BinState bs;
-        if (!hsr_bin_resolve(ref, *ref.R_dev, &bs)) return;
-        keys = bs.keys; vals = bs.vals; keys_alt = bs.keys_unsorted; vals_alt = bs.vals_unsorted;
-    }
-    __shared__ uint64_t comp[TS_MAX];
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t wcnt[4][256];
-    const uint2 rg = ranges[blockIdx.x];
+    const uint2 rg = ranges[tile];
     const int r0 = (int)rg.x, n = (int)(rg.y - rg.x);
     const int t = threadIdx.x;
-    // composite_in (direct binning): keys[] holds (depth bits << 32) | index per instance, the tile is the workgroup's
-    const uint64_t my_tile_hi = (uint64_t)blockIdx.x << 32;
+    // composite_in (direct binning): keys[] holds (depth bits << 32) | index per instance, the tile is given
+    const uint64_t my_tile_hi = (uint64_t)tile << 32;
     if (n <= 0) return;
-    if (composite_in == 2) {   // tiles of at most TW_MAX entries belong to tile_sort_wave_kernel
-        if (n <= 512) return;
-        composite_in = 1;
-    }
     if (n == 1 || n > TS_MAX) {
         if (composite_in) {
             for (int i = t; i < n; i += 256) {
@@ -316,6 +306,26 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
         keys[r0 + i] = tile_hi | (c >> 32);
         vals[r0 + i] = (uint32_t)c;
     }
+}
+
+__global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
+                                                        uint32_t* __restrict__ vals_alt, int gid_passes, int composite_in, BinDevRef ref)
+{
+    if (ref.base) {   // speculative forward: the arrays live where num_rendered says
+        BinState bs;
+        if (!hsr_bin_resolve(ref, *ref.R_dev, &bs)) return;
+        keys = bs.keys; vals = bs.vals; keys_alt = bs.keys_unsorted; vals_alt = bs.vals_unsorted;
+    }
+    __shared__ uint64_t comp[TS_MAX];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wcnt[4][256];
+    if (composite_in == 2) {   // direct binning, tiles of at most TW_MAX entries belong to tile_sort_wave_kernel
+        const uint2 rg = ranges[blockIdx.x];
+        if (rg.y - rg.x <= 512u) return;
+        composite_in = 1;
+    }
+    block_sort_tile((int)blockIdx.x, ranges, keys, vals, keys_alt, vals_alt, gid_passes, composite_in, comp, hist, wcnt);
 }
 
 // ---- per-tile sort, one WAVE per tile, for tiles of at most 512 entries (direct binning composites) ----
@@ -394,25 +404,48 @@ __device__ __forceinline__ void wave_sort_tile(int r0, int n, int lane, uint64_t
     }
 }
 
+// Four tiles per workgroup: each wave sorts its tile if it has at most TW_MAX entries; the larger ones of the four are then
+// sorted one after the other by the whole workgroup (block_sort_tile) in the same launch.
 __global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ vals, BinDevRef ref)
+                                                             uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
+                                                             uint32_t* __restrict__ vals_alt, int gid_passes, int big_too, BinDevRef ref)
 {
-    __shared__ ulonglong2 s_buf[4][4 * 64];   // per wave: E/2 <= 4 rows of 64 x 16 bytes
+    // wave phase: per wave E/2 <= 4 rows of 64 x 16 bytes; workgroup phase: comp[TS_MAX], hist[256], wcnt[4][256]
+    constexpr int RAW = TS_MAX * 8 + 256 * 4 + 4 * 256 * 4;
+    static_assert(RAW >= 4 * 4 * 64 * 16, "the wave buffers alias the workgroup arrays");
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[RAW];
+    __shared__ int s_big[4];
     if (ref.base) {   // speculative forward: the arrays live where num_rendered says
         BinState bs;
         if (!hsr_bin_resolve(ref, *ref.R_dev, &bs)) return;
-        keys = bs.keys; vals = bs.vals;
+        keys = bs.keys; vals = bs.vals; keys_alt = bs.keys_unsorted; vals_alt = bs.vals_unsorted;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wv;
-    if (tile >= T) return;
-    const uint2 rg = ranges[tile];
-    const int r0 = (int)rg.x, n = (int)(rg.y - rg.x);
-    if (n <= 0 || n > TW_MAX) return;
-    const uint64_t tile_hi = (uint64_t)tile << 32;
-    if (n <= 128) wave_sort_tile<2>(r0, n, lane, tile_hi, keys, vals, s_buf[wv]);
-    else if (n <= 256) wave_sort_tile<4>(r0, n, lane, tile_hi, keys, vals, s_buf[wv]);
-    else wave_sort_tile<8>(r0, n, lane, tile_hi, keys, vals, s_buf[wv]);
+    int n = 0, r0 = 0;
+    if (tile < T) {
+        const uint2 rg = ranges[tile];
+        r0 = (int)rg.x;
+        n = (int)(rg.y - rg.x);
+    }
+    if (lane == 0) s_big[wv] = n > TW_MAX;
+    if (n > 0 && n <= TW_MAX) {
+        ulonglong2* buf = reinterpret_cast<ulonglong2*>(s_raw) + wv * (4 * 64);
+        const uint64_t tile_hi = (uint64_t)tile << 32;
+        if (n <= 128) wave_sort_tile<2>(r0, n, lane, tile_hi, keys, vals, buf);
+        else if (n <= 256) wave_sort_tile<4>(r0, n, lane, tile_hi, keys, vals, buf);
+        else wave_sort_tile<8>(r0, n, lane, tile_hi, keys, vals, buf);
+    }
+    if (!big_too) return;   // the larger tiles have a launch of their own (one workgroup per tile)
+    __syncthreads();
+    uint64_t* comp = reinterpret_cast<uint64_t*>(s_raw);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(s_raw + TS_MAX * 8);
+    uint32_t (*wcnt)[256] = reinterpret_cast<uint32_t (*)[256]>(s_raw + TS_MAX * 8 + 256 * 4);
+    for (int w = 0; w < 4; w++) {
+        if (!s_big[w]) continue;
+        block_sort_tile(blockIdx.x * 4 + w, ranges, keys, vals, keys_alt, vals_alt, gid_passes, 1, comp, hist, wcnt);
+        __syncthreads();
+    }
 }
 
 // Sorts the R pairs on key bits [0, end_bit) — the contract of the reference's cub::DeviceRadixSort::SortPairs
@@ -458,7 +491,7 @@ int hsr_launch_sort_pairs(BinState& b, int R, int end_bit, int T, uint2* ranges,
 
 // Per-tile sort alone, for segments in ARBITRARY order holding the 8-byte composites written by direct tile binning
 // (hsr_launch_bin_tiles): tiles above TS_MAX entries radix-sort the Gaussian-index bytes before the depth bytes.
-int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream, const BinDevRef* ref)
+int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream, const BinDevRef* ref, int avg_per_tile_hint)
 {
     int bits = 0;
     while (bits < 32 && (1ull << bits) < (unsigned long long)(P > 1 ? P : 1)) bits++;
@@ -468,8 +501,13 @@ int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStre
         tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 1, r);
         return HSR_OK;
     }
-    // tiles of <= 512 entries: one wave each, elements in registers; the rest: the block-wide LDS network / radix
-    tile_sort_wave_kernel<<<(T + 3) / 4, 256, 0, stream>>>(T, ranges, b.keys, b.vals, r);
-    tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 2, r);
+    // tiles of <= 512 entries: one wave each, elements in registers; the larger ones by whole workgroups — in the same launch
+    // (four tiles per workgroup, one after the other) while they are the exception, in a launch of their own (one workgroup
+    // per tile) when the previous frame averaged more than 400 entries per tile
+    const bool many_big = avg_per_tile_hint > 400;
+    tile_sort_wave_kernel<<<(T + 3) / 4, 256, 0, stream>>>(T, ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8,
+                                                           many_big ? 0 : 1, r);
+    if (many_big)
+        tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 2, r);
     return HSR_OK;
 }
