@@ -192,3 +192,26 @@ def test_ctypes_glue_matches_too():
 def test_compiled_glue_is_loaded():
     from diff_gaussian_rasterization import _C
     assert _C._ext is not None, "diff_gaussian_rasterization._hsr_torch is not built (python hier-slam_amd/csrc/build_torch_ext.py)"
+
+
+def test_radix_binning_path_matches():
+    """HSR_SORT_IMPL=radix: emission in Gaussian order + stable tile-bit radix passes + per-tile sort (the path images of more
+    than 8192 tiles take) instead of direct tile binning — same sorted keys, values, ranges and offsets, bit for bit."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
+            "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
+            "for n in ('replica_tree_k26','plain_mask','huge_splats','deep_tiles_3000')];print('ok')")
+    env = dict(os.environ, HSR_SORT_IMPL="radix")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_more_than_8192_tiles_take_the_radix_path():
+    """2064 x 1040 = 129 x 65 = 8385 tiles: beyond the LDS tile counters of the direct binning, so the library switches to the
+    radix path by itself; state and outputs against the oracle as everywhere else."""
+    import scenes
+    from test_gpu_parity import _compare
+    cam, sc, up = scenes.build(2064, 1040, 4000, 5, seed=3, kind="slam", scale_mult=3.0, bg=(0, 0, 0), behind_frac=0.0)
+    _compare(cam, sc, up, True, "sr", None)
