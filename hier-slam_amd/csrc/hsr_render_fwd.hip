@@ -69,8 +69,10 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
     const TileGeom tg = SUB ? tile_geom_sub(tile, a.W, a.H, t) : tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
     const size_t N = (size_t)a.W * a.H;
-    const size_t pix_id = (size_t)a.W * tg.py + tg.px;
-    const float pfx = tg.pfx, pfy = tg.pfy;
+    // the pixel's coordinates live as FLOATS through the blend loop (opaque to the compiler, which would otherwise keep the
+    // integers and convert them again for every list entry); the integer pixel index is re-derived for the final stores
+    float pfx = tg.pfx, pfy = tg.pfy;
+    asm volatile("" : "+v"(pfx), "+v"(pfy));
     const float tile_x0 = (float)(tg.tx * HSR_TILE_X), tile_y0 = (float)(tg.ty * HSR_TILE_Y);
 
     const uint2 range = a.ranges[tile];
@@ -178,11 +180,18 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
             const int m = max(max(__builtin_amdgcn_readlane(total, 0), __builtin_amdgcn_readlane(total, 16)),
                               max(__builtin_amdgcn_readlane(total, 32), __builtin_amdgcn_readlane(total, 48)));
             const uint8_t* list = s_sublist + sb * HSR_SUB_LSTRIDE;
-            int j_next = total > 0 ? (int)list[0] : 0;   // a group past the end of its list re-reads slot 0 (always staged), weight 0
+            // a group past the end of its list keeps re-reading its last entry, with weight 0 (an empty list is given the always
+            // staged slot 0 as its only entry): an unconditional clamped read instead of a masked one
+            if (total == 0 && (lane & 15) == 0) s_sublist[sb * HSR_SUB_LSTRIDE] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int last = max(total - 1, 0);
+            int j_next = (int)list[0];
             for (int k = 0; k < m; k++) {
                 const int j = j_next;
                 const bool valid = k < total;
-                j_next = (k + 1 < total) ? (int)list[k + 1] : 0;
+                j_next = (int)list[min(k + 1, last)];
                 const float4 g = s_geo[j];
                 const float2 co = s_co[j];
                 const float dx = g.x - pfx, dy = g.y - pfy;
@@ -273,6 +282,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
     }
 
     if (inside) {
+        const size_t pix_id = (size_t)a.W * (size_t)(int)pfy + (size_t)(int)pfx;
         if (BASE) {
             a.final_T[pix_id] = T;
             a.n_contrib[pix_id] = last_contributor;
