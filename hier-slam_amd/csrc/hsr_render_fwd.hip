@@ -177,8 +177,8 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
             // four lists per wave, one per 16-lane group; the wave iterates to the longest of them
             const int lane = t & 63, sb = wv * 4 + (lane >> 4);
             const int total = flatten_sublist(sb, lane, s_sublist, s_subcnt);
-            const int m = max(max(__builtin_amdgcn_readlane(total, 0), __builtin_amdgcn_readlane(total, 16)),
-                              max(__builtin_amdgcn_readlane(total, 32), __builtin_amdgcn_readlane(total, 48)));
+            const int m = __builtin_amdgcn_readfirstlane(max(max(__builtin_amdgcn_readlane(total, 0), __builtin_amdgcn_readlane(total, 16)),
+                                                             max(__builtin_amdgcn_readlane(total, 32), __builtin_amdgcn_readlane(total, 48))));
             const uint8_t* list = s_sublist + sb * HSR_SUB_LSTRIDE;
             // a group past the end of its list keeps re-reading its last entry, with weight 0 (an empty list is given the always
             // staged slot 0 as its only entry): an unconditional clamped read instead of a masked one
