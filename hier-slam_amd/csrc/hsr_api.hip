@@ -402,19 +402,22 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         hsr_set_error("state buffers from the forward call are required");
         return HSR_ERR_INVALID_ARGUMENT;
     }
+    // geometry-only call: no gradient wanted for colours, opacities and semantics (all three NULL) — a tracking iteration;
+    // needs precomputed colours (with SH colours the view direction carries dL_dcolor into dL_dmean3D) and a scratch buffer
+    const bool geo_request = !in.dL_dcolor && !in.dL_dopacity && !in.dL_dsemantics && in.colors_precomp != nullptr;
     if (!in.dL_dpix || !in.dL_dpix_depth || !in.dL_dpix_median || !in.dL_dpix_opacity ||
-        (in.semantic && in.K > 0 && (!in.dL_dpix_sem || !in.dL_dsemantics))) {
+        (in.semantic && in.K > 0 && !geo_request && (!in.dL_dpix_sem || !in.dL_dsemantics))) {
         hsr_set_error("an upstream-gradient pointer is NULL");
         return HSR_ERR_INVALID_ARGUMENT;
     }
     // dL_dconic, dL_ddepth (intermediates the reference keeps to itself, rasterize_points.cu:380-383) and dL_dcov3D may be
     // NULL = not wanted, as long as a scratch buffer carries the accumulation (checked below for the legacy mode)
-    if (!in.dL_dmean2D || !in.dL_dopacity || !in.dL_dcolor || !in.dL_dmean3D) {
+    if (!in.dL_dmean2D || !in.dL_dmean3D || (!geo_request && (!in.dL_dopacity || !in.dL_dcolor))) {
         hsr_set_error("a gradient output pointer is NULL");
         return HSR_ERR_INVALID_ARGUMENT;
     }
-    if (in.scales && (!in.rotations || !in.dL_dscale || !in.dL_drot)) {
-        hsr_set_error("scales given without rotations / dL_dscale / dL_drot");
+    if (in.scales && !in.rotations) {   // dL_dscale / dL_drot may be NULL: not wanted
+        hsr_set_error("scales given without rotations");
         return HSR_ERR_INVALID_ARGUMENT;
     }
     if (!in.background) {
@@ -438,9 +441,14 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     const bool want_rows = rows_mode_requested();
     const bool use_rows = want_rows && in.scratch && hsr_rows_supported(K) && in.R > 0 &&
                           in.scratch_bytes >= hsr_backward_scratch_bytes(P, K, in.R);
-    const int gstride = hsr_grow_stride(K);
+    int gstride = hsr_grow_stride(K);
     const bool use_packed = !use_rows && backward_mode() != 2 && in.scratch &&
                             in.scratch_bytes >= (size_t)P * gstride * sizeof(float) + 256;
+    const bool geo = geo_request && use_packed && (size_t)P * 16 < ((size_t)1 << 30);
+    if (geo_request && !geo) {
+        hsr_set_error("dL_dcolor / dL_dopacity / dL_dsemantics may only all be NULL (geometry-only gradients) in the packed accumulation mode");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
     if (!use_rows && !use_packed && (!in.dL_dconic || !in.dL_ddepth)) {
         hsr_set_error("dL_dconic and dL_ddepth may only be NULL when a scratch buffer carries the accumulation (packed / rows mode)");
         return HSR_ERR_INVALID_ARGUMENT;
@@ -457,6 +465,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         if (!in.colors_precomp && in.shs && in.dL_dsh && in.M > 0)
             HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsh, 0, sizeof(float) * 3 * (size_t)in.M * (size_t)P, stream));
     } else if (use_packed) {
+        if (geo) gstride = 16;   // one 64-byte line per Gaussian: columns 0..6
         char* sp = in.scratch;
         take(sp, grow, (size_t)P * gstride);
         StageTimer tm(HSR_STAGE_BWD_ZERO, stream);
@@ -490,6 +499,8 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
             const int tiles_x = (W + HSR_TILE_X - 1) / HSR_TILE_X, tiles_y = (H + HSR_TILE_Y - 1) / HSR_TILE_Y;
             hsr_launch_inverse_map(in.R, tiles_x, tiles_y, b.keys, b.vals, g.means2D, radii, g.point_offsets, inv, stream);
             rows_kc = hsr_launch_render_backward_rows(ra, stream);
+        } else if (geo) {
+            hsr_launch_render_backward_geo(ra, stream);
         } else {
             hsr_launch_render_backward(ra, stream);
         }
@@ -509,7 +520,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     pb.rows_kc = rows_kc; pb.K = K; pb.rows = rows; pb.inv = inv; pb.point_offsets = g.point_offsets;
     pb.out_mean2D = in.dL_dmean2D; pb.out_conic = in.dL_dconic; pb.out_opacity = in.dL_dopacity; pb.out_color = in.dL_dcolor;
     pb.out_semantics = in.dL_dsemantics; pb.out_depth = in.dL_ddepth;
-    pb.grow = grow; pb.grow_stride = gstride;
+    pb.grow = grow; pb.grow_stride = gstride; pb.geo = geo ? 1 : 0;
     if (pb.shs && (!in.dL_dsh || !in.campos)) {
         hsr_set_error("shs given without dL_dsh / campos");
         return HSR_ERR_INVALID_ARGUMENT;
@@ -592,6 +603,8 @@ size_t hsr_backward_scratch_bytes(int P, int K, int num_rendered)
 }
 
 const char* hsr_last_error(void) { return g_err; }
+
+int hsr_get_backward_mode(void) { return backward_mode(); }
 
 int hsr_set_backward_mode(int mode)
 {

@@ -115,7 +115,7 @@ template <int KC>
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (KC < 0 && a.grow && a.K > 0) {
+    if (KC < 0 && a.grow && a.K > 0 && a.out_semantics) {
         // packed mode: the block unpacks the semantic columns of its 256 rows cooperatively — consecutive
         // lanes read consecutive floats of a row and write one contiguous [256, K] slab of dL_dsemantics
         const int g0 = blockIdx.x * 256;
@@ -157,14 +157,17 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
         // packed mode: unpack this Gaussian's atomically accumulated row into the reference's arrays
         const float4* r = reinterpret_cast<const float4*>(a.grow + (size_t)idx * a.grow_stride);
         const float4 r0 = r[0], r1 = r[1];
-        const float* dr = a.grow + (size_t)idx * a.grow_stride + hsr_grow_direct0(a.K);  // r, g, b, depth, opacity (direct)
-        const float d_r = dr[0], d_g = dr[1], d_b = dr[2], d_dep = dr[3], d_op = dr[4];
+        float d_r = 0.f, d_g = 0.f, d_b = 0.f, d_dep = 0.f, d_op = 0.f;
+        if (!a.geo) {
+            const float* dr = a.grow + (size_t)idx * a.grow_stride + hsr_grow_direct0(a.K);  // r, g, b, depth, opacity (direct)
+            d_r = dr[0]; d_g = dr[1]; d_b = dr[2]; d_dep = dr[3]; d_op = dr[4];
+        }
         g_m2x = r0.x; g_m2y = r0.y; g_cx = r0.z; g_cy = r0.w; g_cw = r1.x;
         g_depth = r1.z + d_dep;
         a.out_mean2D[3 * idx] = g_m2x; a.out_mean2D[3 * idx + 1] = g_m2y; a.out_mean2D[3 * idx + 2] = 0.f;
         if (a.out_conic) reinterpret_cast<float4*>(a.out_conic)[idx] = make_float4(g_cx, g_cy, 0.f, g_cw);
-        a.out_opacity[idx] = r1.y + d_op;
-        a.out_color[3 * idx] = d_r; a.out_color[3 * idx + 1] = d_g; a.out_color[3 * idx + 2] = d_b;
+        if (a.out_opacity) a.out_opacity[idx] = r1.y + d_op;
+        if (a.out_color) { a.out_color[3 * idx] = d_r; a.out_color[3 * idx + 1] = d_g; a.out_color[3 * idx + 2] = d_b; }
         if (a.out_depth) a.out_depth[idx] = g_depth;
     } else {
         g_m2x = a.dL_dmean2D[3 * idx]; g_m2y = a.dL_dmean2D[3 * idx + 1];

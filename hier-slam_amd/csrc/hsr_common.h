@@ -189,6 +189,7 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream);
 int hsr_launch_render_backward_mfma(const RenderBwdArgs& a, hipStream_t stream);
 int hsr_launch_render_backward_mom(const RenderBwdArgs& a, hipStream_t stream);   // K <= 27, packed mode: all sums on MFMA
 int hsr_launch_render_backward_sub(const RenderBwdArgs& a, hipStream_t stream);   // K <= 27, packed mode: 4x4 sub-block lists, rows merged per tile in LDS
+int hsr_launch_render_backward_geo(const RenderBwdArgs& a, hipStream_t stream);   // packed mode, geometry gradients only (grow_stride 16)
 int hsr_launch_render_backward_subw(const RenderBwdArgs& a, hipStream_t stream);  // K > 27, packed mode: sub-block masks, channel passes
 int hsr_launch_render_backward_wide(const RenderBwdArgs& a, hipStream_t stream);  // semantic, K > 27: matrix-core channel passes
 int hsr_launch_render_backward_rows(const RenderBwdArgs& a, hipStream_t stream);  // returns the kernel's KC
@@ -231,6 +232,7 @@ struct PreBwdArgs {
     // packed mode: one atomically accumulated row per Gaussian (see hsr_grow_* in hsr_tile_common.h)
     const float* grow;
     int grow_stride;
+    int geo;                 // geometry-only rows (16 floats: columns 0..6, depth complete in column 6); out_color / out_opacity / out_semantics NULL
 };
 int hsr_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t stream);
 

@@ -317,6 +317,209 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     }
 }
 
+// Geometry-only variant: the caller wants no gradient for colours, opacities or semantics (a TRACKING iteration of Hier-SLAM:
+// only the camera pose is optimised, scripts/hierslam.py:1683-1860, so autograd asks for dL_dmeans3D / dL_dmeans2D alone).
+// Then no sum of the form sum_pixels w*g is needed except the depth one, which joins the median-depth term in column 6:
+// no upstream semantic gradients are read, no panel, no matrix cores, and a row is ONE 64-byte line (columns 0..6 of a
+// 16-float row) instead of three — a third of the atomic requests.
+template <int BATCH>
+__global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
+{
+    static_assert(BATCH <= 256, "batch slots are bytes");
+    __shared__ float4 s_geo[BATCH];
+    __shared__ float2 s_co[BATCH];
+    __shared__ float4 s_col[BATCH];
+    __shared__ int s_id[BATCH];
+    __shared__ uint16_t s_mask[BATCH];                  // sub-block mask of each staged splat
+    __shared__ uint8_t s_list[4][256];
+    __shared__ uint8_t s_lcnt[4][4];
+    __shared__ uint8_t s_flat[4][256];
+    __shared__ int s_wmax[4];
+    __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
+    __shared__ int s_cid[4][SB_SLOTS];                  // Gaussian id of each chunk row
+    __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
+
+    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, gq = lane >> 4, l16 = lane & 15;
+    const TileGeom tg = tile_geom_sub(tile, a.W, a.H, t);
+    const bool inside = tg.inside;
+    const size_t N = (size_t)a.W * a.H;
+    const size_t pix_id = (size_t)a.W * tg.py + tg.px;
+    const float pfx = tg.pfx, pfy = tg.pfy;
+    const float tile_x0 = (float)(tg.tx * HSR_TILE_X), tile_y0 = (float)(tg.ty * HSR_TILE_Y);
+    const uint2 range = a.ranges[tile];
+    float* u7 = s_u7[wv];
+
+    // every prologue load unconditional and issued before anything consumes one (see hsr_render_bwd_mfma.hip)
+    const size_t pix_ld = inside ? pix_id : 0;
+    const float inm = inside ? 1.f : 0.f;
+    const float T_final_ld = a.final_T[pix_ld];
+    const int last_contributor_ld = (int)a.n_contrib[pix_ld];
+    float dpx0 = a.dL_dpix[pix_ld], dpx1 = a.dL_dpix[N + pix_ld], dpx2 = a.dL_dpix[2 * N + pix_ld];
+    float dpd = a.dL_dpix_depth[pix_ld], dpm = a.dL_dpix_median[pix_ld], dpo = a.dL_dpix_opacity[pix_ld];
+    dpx0 *= inm; dpx1 *= inm; dpx2 *= inm; dpd *= inm; dpm *= inm; dpo *= inm;
+    const float T_final = T_final_ld * inm;
+    float T = T_final;
+    const int last_contributor = inside ? last_contributor_ld : 0;
+
+    int wmax = last_contributor;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) s_wmax[wv] = wmax;
+
+    __syncthreads();
+    const int hi_all = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+
+    const float bg_dot = a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2;
+    const float kx = (0.5f * a.W) / HSR_LOG2E, ky = (0.5f * a.H) / HSR_LOG2E;
+    float Rb = 0.f, last_h = 0.f, last_alpha = 0.f;
+
+    // butterfly value this lane holds after row_reduce_transpose7, or -1
+    const int myv = (lane & 2) ? -1 : (((lane >> 2) & 3) | ((lane & 1) << 2));
+    const bool myv_on = myv >= 0 && myv < SB_NV;
+    // zeroes the panel rows and the butterfly slots of the next chunk (wave-private LDS: no barrier)
+    auto clear_chunk = [&]() {
+        float4* u4 = reinterpret_cast<float4*>(u7);
+#pragma unroll
+        for (int i = 0; i < (SB_SLOTS * 4 * 8) / 4; i += 64) u4[i + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // the chunk's 16 panel rows -> D[16 entries][16*NG channels] -> packed rows; butterfly slots -> columns 0..6
+    auto flush = [&](int nrows) {
+        // butterfly columns 0..6: two wave-instructions of 8 rows x 7 values, so that each row's line is ONE request
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
+            const float* src = u7 + row * 32 + vi;
+            const float val = (src[0] + src[8]) + (src[16] + src[24]);
+            const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride + (uint32_t)vi;
+            if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
+        }
+    };
+
+    // ---- software-pipelined staging ----
+    int id_next = 0, id_cur = 0;
+    float2 p_xy = {0, 0};
+    float4 p_co = {0, 0, 0, 0};
+    float p_r = 0, p_g = 0, p_b = 0, p_d = 0;
+    auto load_id = [&](int hi) {
+        if (t < BATCH && hi - 1 - t >= 0) id_next = (int)a.point_list[range.x + hi - 1 - t];
+    };
+    auto load_record = [&](int hi) {
+        if (t < BATCH && hi - 1 - t >= 0) {
+            const size_t id = (size_t)id_next;
+            id_cur = id_next;
+            if (a.rec) {
+                const float4* rec = a.rec + 4 * id;
+                const float4 r0 = rec[0], r2 = rec[2];
+                p_co = rec[1];
+                p_xy = make_float2(r0.x, r0.y);
+                p_d = r0.z;
+                p_r = r2.x; p_g = r2.y; p_b = r2.z;
+            } else {
+                p_xy = a.means2D[id];
+                p_co = a.conic_opacity[id];
+                p_r = a.colors[3 * id];
+                p_g = a.colors[3 * id + 1];
+                p_b = a.colors[3 * id + 2];
+                p_d = a.depths[id];
+            }
+        }
+    };
+    load_id(hi_all);
+    load_record(hi_all);
+    load_id(hi_all - BATCH);
+
+    for (int hi = hi_all; hi > 0; hi -= BATCH) {
+        const int cnt = min(BATCH, hi);
+        __syncthreads();
+        uint32_t qmask = 0u;
+        if (t < cnt) {
+            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
+            qmask = (uint32_t)((mask & 0xFu) != 0u) | ((uint32_t)((mask & 0xF0u) != 0u) << 1) | ((uint32_t)((mask & 0xF00u) != 0u) << 2) |
+                    ((uint32_t)((mask & 0xF000u) != 0u) << 3);
+            s_mask[t] = (uint16_t)mask;
+            s_id[t] = id_cur;
+            s_geo[t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
+            s_co[t] = make_float2((-0.5f * HSR_LOG2E) * p_co.z, p_co.w);
+            s_col[t] = make_float4(p_r, p_g, p_b, p_d);
+        }
+        publish_quadrant_lists(qmask, t, s_list, s_lcnt);
+        __syncthreads();
+        load_record(hi - BATCH);
+        load_id(hi - 2 * BATCH);
+        if (hi - cnt >= wmax) continue;   // this wave's pixels all stopped in front of this batch
+
+        const int total = build_flat_list(wv, lane, s_list, s_lcnt, s_flat);
+        for (int c0 = 0; c0 < total; c0 += SB_SLOTS) {
+            const int nrows = min(SB_SLOTS, total - c0);
+            // lane (group gq, row l16): does chunk entry l16 touch sub-block (wv, gq)?
+            const int jr = l16 < nrows ? (int)s_flat[wv][c0 + l16] : 0;
+            const bool touch = l16 < nrows && ((s_mask[jr] >> (4 * wv + gq)) & 1u);
+            const uint64_t ball = __ballot(touch);
+            if (gq == 0) {
+                s_cj[wv][l16] = (uint8_t)jr;
+                s_cid[wv][l16] = s_id[jr];
+            }
+            clear_chunk();
+            const int iters = max(max(__popc((uint32_t)ball & 0xFFFFu), __popc((uint32_t)(ball >> 16) & 0xFFFFu)),
+                                  max(__popc((uint32_t)(ball >> 32) & 0xFFFFu), __popc((uint32_t)(ball >> 48))));
+            uint32_t todo = (uint32_t)(ball >> (16 * gq)) & 0xFFFFu;   // this group's entries, visited in list order
+            int r_next = todo ? __builtin_ctz(todo) : 0;
+            int j_next = s_cj[wv][r_next];
+            for (int it = 0; it < iters; it++) {
+                const bool valid = todo != 0u;
+                const int r = r_next, j = j_next;
+                todo &= todo - 1u;
+                r_next = todo ? __builtin_ctz(todo) : 0;
+                j_next = s_cj[wv][r_next];
+                const float4 g = s_geo[j];
+                const float2 co = s_co[j];
+                const float4 cd = s_col[j];
+                asm volatile("" ::"v"(cd.x), "v"(cd.y), "v"(cd.z), "v"(cd.w));
+                const int pos = hi - 1 - j;
+                const float dx = g.x - pfx, dy = g.y - pfy;
+                const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
+                const float power2 = fmaf(co.x, dyy, fmaf(g.w, dxy, g.z * dxx));
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float alpha = fminf(0.99f, co.y * G);
+                const bool active = valid && pos < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+                if (__ballot(active) == 0ull) continue;
+
+                const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float test_T = T * inv_one_m_a;
+                const float w = active ? alpha * test_T : 0.f;
+
+                const float h = fmaf(cd.x, dpx0, fmaf(cd.y, dpx1, fmaf(cd.z, dpx2, fmaf(cd.w, dpd, dpo))));
+                const float Rn = fmaf(last_alpha, last_h - Rb, Rb);
+                float dL_dalpha = (h - Rn) * test_T;
+                dL_dalpha += (-T_final * inv_one_m_a) * bg_dot;
+                const float Gs = active ? G : 0.f;
+                const float gda = Gs * dL_dalpha;
+                const float q = co.y * gda;
+                float v[SB_NV];
+                v[0] = q * fmaf(2.0f * g.z, dx, g.w * dy) * kx;
+                v[1] = q * fmaf(2.0f * co.x, dy, g.w * dx) * ky;
+                const float hq = -0.5f * q;
+                v[2] = hq * dxx;
+                v[3] = hq * dxy;
+                v[4] = hq * dyy;
+                v[5] = gda;
+                v[6] = fmaf(w, dpd, (active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f);   // depth: direct sum + median term
+                if (active) {
+                    Rb = Rn;
+                    last_h = h;
+                    last_alpha = alpha;
+                    T = test_T;
+                }
+                const float total7 = row_reduce_transpose7(v, lane);
+                if (myv_on && valid) u7[r * 32 + gq * 8 + myv] = total7;
+            }
+            flush(nrows);
+        }
+    }
+}
+
 // Wide trees (K > 27), in channel passes like hsr_render_bwd_wide.hip: semantic channels [c0, c0 + ns) of the image; the BASE
 // pass adds the five direct sums and the seven butterfly values, a SEM pass only re-derives alpha and T and feeds the panel.
 // 16 * NG >= ns + (BASE ? 5 : 0).
@@ -615,6 +818,14 @@ void launch_subw_pass(const RenderBwdArgs& a, int c0, int ns, dim3 grid, hipStre
     else render_bwd_subw_kernel<4, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
 }
 }  // namespace
+
+// geometry-only gradients (a.grow_stride == 16): any K
+int hsr_launch_render_backward_geo(const RenderBwdArgs& a, hipStream_t stream)
+{
+    const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
+    render_bwd_geo_kernel<224><<<dim3(hsr_tile_grid(tiles)), dim3(256), 0, stream>>>(a);
+    return HSR_OK;
+}
 
 // semantic variant with K > 27, packed mode, P * grow_stride < 2^30: BASE pass (59 channels + the base sums) + SEM passes of 64
 int hsr_launch_render_backward_subw(const RenderBwdArgs& a, hipStream_t stream)

@@ -147,7 +147,7 @@ backward_common(bool semantic, const OptT& background, const at::Tensor& means3D
                 const OptT& dL_dout_semantic, const at::Tensor& dL_dout_depth, const at::Tensor& dL_dout_median_depth,
                 const at::Tensor& dL_dout_final_opacity, const OptT& sh, int64_t degree, const OptT& campos,
                 const at::Tensor& geomBuffer, int64_t R, const at::Tensor& binningBuffer, const at::Tensor& imageBuffer, bool debug,
-                bool want_cov3D_grad, int64_t stream)
+                bool want_cov3D_grad, bool geometry_only, int64_t stream)
 {
     TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization: tensors must live on a HIP device (got ", means3D.device(),
                 "); this build has no CPU path");
@@ -158,15 +158,20 @@ backward_common(bool semantic, const OptT& background, const at::Tensor& means3D
     c10::DeviceGuard guard(dev);
     const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
     auto fresh = [&](at::IntArrayRef shape) { return P == 0 ? at::zeros(shape, fopt) : at::empty(shape, fopt); };   // fully overwritten when P > 0
-    at::Tensor dL_dmeans3D = fresh({P, 3}), dL_dmeans2D = fresh({P, 3}), dL_dcolors = fresh({P, NUM_CHANNELS});
-    at::Tensor dL_dsemantics = fresh({P, K}), dL_dopacity = fresh({P, 1}), dL_dsh = fresh({P, M, 3});
-    at::Tensor dL_dscales = fresh({P, 3}), dL_drotations = fresh({P, 4});
     // with a scratch buffer dL_dconic and dL_ddepths are intermediates nobody reads (the reference keeps them inside
     // RasterizeGaussiansBackwardCUDA, rasterize_points.cu:380-383): not allocated, not written
     const size_t nscratch = P ? hsr_backward_scratch_bytes((int)P, (int)K, (int)R) : 0;
+    // geometry-only (tracking iteration): no gradient wanted for colours, opacities, semantics, scales, rotations, SH, cov3D
+    const bool geo = geometry_only && nscratch && hsr_get_backward_mode() == 0 && colors.has_value() && colors->defined() && colors->numel() != 0;
+    at::Tensor dL_dmeans3D = fresh({P, 3}), dL_dmeans2D = fresh({P, 3});
+    at::Tensor dL_dcolors, dL_dsemantics, dL_dopacity, dL_dsh, dL_dscales, dL_drotations;
+    if (!geo) {
+        dL_dcolors = fresh({P, NUM_CHANNELS}); dL_dsemantics = fresh({P, K}); dL_dopacity = fresh({P, 1}); dL_dsh = fresh({P, M, 3});
+        dL_dscales = fresh({P, 3}); dL_drotations = fresh({P, 4});
+    }
     at::Tensor dL_dconic, dL_ddepths, dL_dcov3D, scratch;
     if (!nscratch) { dL_dconic = fresh({P, 2, 2}); dL_ddepths = fresh({P, 1}); }
-    if (want_cov3D_grad || P == 0) dL_dcov3D = fresh({P, 6});
+    if ((want_cov3D_grad && !geo) || P == 0) dL_dcov3D = fresh({P, 6});
     if (P != 0) {
         const at::Tensor bg_ = prep(background, dev), m3_ = prep(means3D, dev), sh_ = prep(sh, dev), col_ = prep(colors, dev);
         const at::Tensor sem_ = semantic ? prep(semantics, dev) : at::Tensor();

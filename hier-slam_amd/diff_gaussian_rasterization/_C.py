@@ -77,6 +77,8 @@ def _load():
     lib.hsr_stage_name.argtypes = [ci]
     lib.hsr_profile_enable.restype = ci
     lib.hsr_profile_enable.argtypes = [ci]
+    lib.hsr_get_backward_mode.restype = ci
+    lib.hsr_get_backward_mode.argtypes = []
     lib.hsr_profile_host_wait_ms.restype = C.c_double
     lib.hsr_profile_host_wait_ms.argtypes = [ci]
     lib.hsr_profile_select.restype = ci
@@ -146,6 +148,10 @@ class _HintMap(dict):
 
 
 _binning_hint = _HintMap()
+
+def _rows_or_legacy():
+    return int(_lib.hsr_get_backward_mode()) != 0
+
 
 def set_backward_mode(mode):
     """'packed' (default), 'rows' (experimental, no global atomics) or 'legacy' (reference-style arrays)."""
@@ -291,6 +297,10 @@ def rasterize_gaussians_semantic(background, means3D, colors, semantics, opacity
 # Cleared by the autograd node for one call when cov3D_precomp needs no gradient (the usual case: Hier-SLAM passes scales and
 # rotations): dL_dcov3D is then neither allocated nor written, and the backward entry points return None in its place.
 want_cov3D_grad = True
+# Set by the autograd node for one call when no gradient is wanted for colours, opacities, semantics, scales, rotations, SH and
+# cov3D (a tracking iteration: only the pose is optimised): the library then forms the geometry sums only and the entry points
+# return None for the rest.
+geometry_only_grads = False
 
 
 def _backward_common(semantic, background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
@@ -302,7 +312,8 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
                                     float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
                                     dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity,
                                     sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug),
-                                    bool(want_cov3D_grad), torch.cuda.current_stream(means3D.device).cuda_stream)
+                                    bool(want_cov3D_grad), bool(geometry_only_grads),
+                                    torch.cuda.current_stream(means3D.device).cuda_stream)
     _require_gpu(means3D)
     dev = means3D.device
     P = int(means3D.size(0))
@@ -311,21 +322,23 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
     K = int(dL_dout_semantic.size(0)) if semantic else 0
     fopt = dict(dtype=torch.float32, device=dev)
     new = torch.zeros if P == 0 else torch.empty  # the library overwrites every element when P > 0
+    packed_ok = P != 0 and int(_lib.hsr_backward_scratch_bytes(P, K, int(R))) > 0 and int(_lib.hsr_backward_scratch_bytes(P, K, 0)) > 0
+    geo = bool(geometry_only_grads) and packed_ok and colors is not None and colors.numel() != 0 and not _rows_or_legacy()
     dL_dmeans3D = new((P, 3), **fopt)
     dL_dmeans2D = new((P, 3), **fopt)
-    dL_dcolors = new((P, NUM_CHANNELS), **fopt)
-    dL_dsemantics = new((P, K), **fopt)
+    dL_dcolors = None if geo else new((P, NUM_CHANNELS), **fopt)
+    dL_dsemantics = None if geo else new((P, K), **fopt)
     # with a scratch buffer (every mode but 'legacy') dL_dconic and dL_ddepths are intermediates nobody reads (the reference
     # keeps them inside RasterizeGaussiansBackwardCUDA, rasterize_points.cu:380-383): not allocated, not written;
     # dL_dcov3D only when the caller wants it (want_cov3D_grad, cleared by the autograd node when cov3D_precomp needs no grad)
     packed_scratch = P != 0 and int(_lib.hsr_backward_scratch_bytes(P, K, int(R))) > 0
     dL_dconic = None if packed_scratch else new((P, 2, 2), **fopt)
     dL_ddepths = None if packed_scratch else new((P, 1), **fopt)
-    dL_dopacity = new((P, 1), **fopt)
-    dL_dcov3D = new((P, 6), **fopt) if (want_cov3D_grad or P == 0) else None
-    dL_dsh = new((P, M, 3), **fopt)
-    dL_dscales = new((P, 3), **fopt)
-    dL_drotations = new((P, 4), **fopt)
+    dL_dopacity = None if geo else new((P, 1), **fopt)
+    dL_dcov3D = new((P, 6), **fopt) if ((want_cov3D_grad and not geo) or P == 0) else None
+    dL_dsh = None if geo else new((P, M, 3), **fopt)
+    dL_dscales = None if geo else new((P, 3), **fopt)
+    dL_drotations = None if geo else new((P, 4), **fopt)
     if P != 0:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream

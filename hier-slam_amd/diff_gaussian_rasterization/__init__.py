@@ -102,10 +102,14 @@ class _Rasterize(torch.autograd.Function):
         mid = (scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
                grad_color)
         _C.want_cov3D_grad = bool(ctx.needs_input_grad[9])   # cov3Ds_precomp
+        # only means3D / means2D want a gradient (a tracking iteration optimises the camera pose alone, scripts/hierslam.py:1683-1860):
+        # the library then forms the geometry sums only — a third of the atomic traffic, no semantic upstream gradients read
+        _C.geometry_only_grads = not any(ctx.needs_input_grad[i] for i in (3, 4, 5, 6, 7, 8, 9))
         try:
             return _Rasterize._run_backward(ctx, rs, head, mid, tail, semantics_precomp, grad_sem, grad_depth, grad_median, grad_opacity)
         finally:
             _C.want_cov3D_grad = True
+            _C.geometry_only_grads = False
 
     @staticmethod
     def _run_backward(ctx, rs, head, mid, tail, semantics_precomp, grad_sem, grad_depth, grad_median, grad_opacity):

@@ -70,6 +70,7 @@ size_t hsr_backward_scratch_bytes(int P, int K, int num_rendered);
  *   1 rows   : per-instance rows + per-Gaussian sum, no global atomics (experimental, K <= 27);
  *   2 legacy : atomics straight into the six output arrays, as the reference does; needs no scratch. */
 int hsr_set_backward_mode(int mode);
+int hsr_get_backward_mode(void);   /* 0 packed, 1 rows, 2 legacy */
 
 /* Thread-local text of the last error returned by any hsr_* call on this thread. */
 const char* hsr_last_error(void);
@@ -110,8 +111,12 @@ int hsr_forward_semantic(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* 
  * R = num_rendered returned by the matching hsr_forward; the three buffers are the ones it filled.
  * dL_dmean2D is [P,3] (z unused), dL_dconic [P,4] (.z unused), dL_dopacity [P], dL_dcolor [P,3],
  * dL_ddepth [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4].
- * dL_dcov3D may be NULL (not wanted); dL_dconic and dL_ddepth — intermediates the reference keeps to itself
- * (rasterize_points.cu:380-383) — may be NULL when `scratch` carries the accumulation (the default).
+ * dL_dcov3D, dL_dscale, dL_drot may be NULL (not wanted); dL_dconic and dL_ddepth — intermediates the reference keeps to
+ * itself (rasterize_points.cu:380-383) — may be NULL when `scratch` carries the accumulation (the default).
+ * Geometry-only call: dL_dcolor, dL_dopacity and dL_dsemantics ALL NULL (with colors_precomp and the default accumulation
+ * mode) = the caller optimises the camera pose only (a tracking iteration, scripts/hierslam.py:1683-1860): the tile kernel
+ * then forms just the mean2D / conic / depth sums — one 64-byte row per Gaussian instead of three, no semantic upstream
+ * gradients read; dL_dmean2D and dL_dmean3D are the same as in a full call.
  * All are fully overwritten.
  * scratch: device buffer of hsr_backward_scratch_bytes(P, K, R) bytes, or NULL.  With it (default accumulation mode,
  * hsr_set_backward_mode) the per-splat sums go by fp32 atomics into ONE packed, 64-byte-aligned row per Gaussian

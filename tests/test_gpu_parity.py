@@ -172,3 +172,48 @@ def test_speculative_forward_and_its_fallback_agree_with_the_oracle(monkeypatch)
     monkeypatch.setitem(_C._binning_hint, key, int(R / 1.25) - 900)   # required bytes just below what R needs
     _compare(cam, sc, up, True, "sr", None)
     assert _C._binning_hint[key] == R
+
+
+@pytest.mark.parametrize("semantic,K", [(True, 26), (True, 74), (False, 0)])
+def test_geometry_only_backward_matches_the_full_one(semantic, K):
+    """When only means3D / means2D want a gradient (a tracking iteration optimises the camera pose alone) the library forms the
+    geometry sums only (hsr_backward*: dL_dcolor, dL_dopacity, dL_dsemantics NULL -> render_bwd_geo_kernel).  dL_dmeans3D and
+    dL_dmeans2D must equal those of a full backward of the same render (to atomics-order noise) and the oracle's (1e-4)."""
+    import torch
+    from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizer_semantic, _C
+    from harness import _cam_to, run_oracle, assert_close
+    W, H, P = 203, 131, 3000
+    cam, sc, up = scenes.build(W, H, P, K, seed=11, kind="slam", scale_mult=3.0)
+    dev = torch.device("cuda:0")
+    camd = _cam_to(cam, dev)
+    grads = {}
+    for mode in ("pose", "full"):
+        means3D = sc["means3D"].to(dev).clone().requires_grad_(True)
+        means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+        rest = {n: sc[n].to(dev).clone().requires_grad_(mode == "full") for n in ("opacities", "colors_precomp", "scales", "rotations")}
+        seen = {}
+        real = _C._lib.hsr_backward_semantic if semantic else _C._lib.hsr_backward
+        if semantic:
+            sem = sc["semantics_precomp"].to(dev).clone().requires_grad_(mode == "full")
+            outs = GaussianRasterizer_semantic(camd)(means3D=means3D, means2D=means2D, opacities=rest["opacities"], colors_precomp=rest["colors_precomp"],
+                                                     scales=rest["scales"], rotations=rest["rotations"], semantics_precomp=sem)
+            color, radii, semantic_map, depth, median, opacity = outs
+            loss = (semantic_map * up["semantic"].to(dev)).sum()
+        else:
+            outs = GaussianRasterizer(camd)(means3D=means3D, means2D=means2D, opacities=rest["opacities"], colors_precomp=rest["colors_precomp"],
+                                            scales=rest["scales"], rotations=rest["rotations"])
+            color, radii, depth, median, opacity, mask = outs
+            loss = 0.0
+        loss = loss + (color * up["color"].to(dev)).sum() + (depth * up["depth"].to(dev)).sum() + (median * up["median"].to(dev)).sum() \
+            + (opacity * up["opacity"].to(dev)).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[mode] = (means3D.grad.cpu().numpy(), means2D.grad.cpu().numpy())
+        if mode == "pose":
+            assert rest["colors_precomp"].grad is None and rest["opacities"].grad is None
+    for a, b, name in ((grads["pose"][0], grads["full"][0], "means3D"), (grads["pose"][1], grads["full"][1], "means2D")):
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), name
+    oo, go, so = run_oracle(cam, sc, up, semantic=semantic, variant="sr")
+    assert_close("means3D (geometry-only) vs oracle", grads["pose"][0], go["means3D"])
+    assert_close("means2D (geometry-only) vs oracle", grads["pose"][1], go["means2D"])

@@ -99,9 +99,13 @@ def measure(P=500000, W=1200, H=680, iters=20):
             iteration(fused, leaf)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters * 1e3
-    def tracking(fused):
-        """scripts/hierslam.py:1683-1860 per iteration: pose gradients only, masked L1 sums on depth and colour"""
+    def tracking(fused, pose_only=False):
+        """scripts/hierslam.py:1683-1860 per iteration: pose gradients only, masked L1 sums on depth and colour.  pose_only: the map
+        tensors are detached (the reference leaves them attached with learning rate 0, so their gradients are computed and thrown
+        away); the rasterizer then runs its geometry-only backward"""
         rv = SH.transformed_params2rendervar_semantic(params, SH.transform_to_frame(params, 1, False, True)) if fused else eager_prep(params, 1)
+        if pose_only:
+            rv = {k: (v if k in ("means3D", "means2D") or v is None else v.detach()) for k, v in rv.items()}
         im, radius, sem, depth, med, opac = GaussianRasterizer_semantic(raster_settings=cam)(**rv)
         mask = ((gt_d > 0) & ~torch.isnan(depth) & (opac > 0.99)).detach()
         if fused:
@@ -111,22 +115,24 @@ def measure(P=500000, W=1200, H=680, iters=20):
         loss.backward()
         return loss
 
-    def time_tracking(fused):
+    def time_tracking(fused, pose_only=False):
         for _ in range(3):
-            tracking(fused)
+            tracking(fused, pose_only)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
             for v in params.values():
                 v.grad = None
-            tracking(fused)
+            tracking(fused, pose_only)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters * 1e3
     lf, le = float(iteration(True).detach()), float(iteration(False).detach())
     return {"workload": "mapping iteration without optimizer: prep + semantic render + mapping losses + backward, %dx%d, P=%d, K=%d" % (W, H, P, K),
             "fused_ms": timeit(True), "eager_around_same_rasterizer_ms": timeit(False), "loss_fused": lf, "loss_eager": le,
             "tracking_iteration": {"note": "pose-only iteration (scripts/hierslam.py:1683-1860): prep with camera_grad, render, masked L1 sums, backward",
-                                   "fused_ms": time_tracking(True), "eager_around_same_rasterizer_ms": time_tracking(False)},
+                                   "fused_ms": time_tracking(True), "eager_around_same_rasterizer_ms": time_tracking(False),
+                                   "fused_map_detached_ms": time_tracking(True, True),
+                                   "note2": "map tensors detached -> geometry-only rasterizer backward (one 64-byte row per Gaussian, no semantic upstream gradients)"},
             "with_leaf_head": {"note": "mapping iterations >= 14 add the 1x1-conv leaf MLP + cross-entropy (scripts/hierslam.py:975-983)",
                                "fused_ms": timeit(True, True), "eager_around_same_rasterizer_ms": timeit(False, True),
                                "loss_fused": float(iteration(True, True).detach()), "loss_eager": float(iteration(False, True).detach())}}
