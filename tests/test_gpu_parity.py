@@ -3,6 +3,8 @@
 Bar (BASELINE.json north_star): radii, tiles_touched, offsets, sorted keys, values and tile ranges
 BIT-EXACT; images and gradients within 1e-4 (fp32).  n_contrib / median depth depend on hard thresholds
 fed by exp(), whose last-ulp differs between glibc and the GPU: compared with a small mismatch budget."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -217,3 +219,35 @@ def test_geometry_only_backward_matches_the_full_one(semantic, K):
     oo, go, so = run_oracle(cam, sc, up, semantic=semantic, variant="sr")
     assert_close("means3D (geometry-only) vs oracle", grads["pose"][0], go["means3D"])
     assert_close("means2D (geometry-only) vs oracle", grads["pose"][1], go["means2D"])
+
+
+def test_backward_argument_checks_in_a_ctypes_child():
+    import subprocess
+    import sys
+    code = r'''
+import sys; sys.path[:0]=['hier-slam_amd','tests']
+import torch, scenes
+from diff_gaussian_rasterization import GaussianRasterizer_semantic, _C
+from harness import _cam_to
+cam, sc, up = scenes.build(96, 64, 500, 5, seed=1, kind="slam")
+dev = torch.device("cuda:0"); camd = _cam_to(cam, dev)
+def run(pose_only):
+    m3 = sc["means3D"].to(dev).clone().requires_grad_(True); m2 = torch.zeros(500, 3, device=dev, requires_grad=True)
+    rest = {n: sc[n].to(dev).clone().requires_grad_(not pose_only) for n in ("opacities", "colors_precomp", "scales", "rotations", "semantics_precomp")}
+    outs = GaussianRasterizer_semantic(camd)(means3D=m3, means2D=m2, opacities=rest["opacities"], colors_precomp=rest["colors_precomp"],
+                                             scales=rest["scales"], rotations=rest["rotations"], semantics_precomp=rest["semantics_precomp"])
+    (outs[0].sum() + outs[3].sum()).backward(); torch.cuda.synchronize(); return m3.grad.clone()
+_C.set_backward_mode("legacy")
+a = run(True)            # geometry-only request in the legacy mode: the glue must fall back to a full backward, not fail
+b = run(False)
+assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+# straight at the C ABI: legacy mode (no scratch) with dL_dconic = NULL is refused
+rc = _C._lib.hsr_backward_semantic(500, 0, 0, 5, 1, None, 96, 64, None, None, None, None, None, 1.0, None, None, None, None, None, 1.0, 1.0,
+                                   None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, 0, 0, None)
+assert rc < 0, rc
+print("ok")
+'''
+    env = dict(os.environ, HSR_GLUE="ctypes")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
