@@ -31,8 +31,7 @@ namespace {
 
 template <int KC>
 struct FwdCfg {
-    // LDS per staged splat: 16 (x,y,cx,cy) + 8 (cz,op) + 16 (r,g,b,depth) + 4*KP
-    static constexpr int KP = (KC + 3) & ~3;
+    // LDS per staged splat: 32 (x, y, A, B, C, opacity, r, g) + 4 * round4(KC + 2) (features, b, depth)
     static constexpr int BATCH = KC <= 32 ? 256 : (KC <= 80 ? 128 : 64);
 };
 
@@ -45,13 +44,15 @@ struct FwdCfg {
 template <int KC, bool BASE, bool MASK, bool ALIGNED, bool SUB = false>
 __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_kernel(RenderFwdArgs a, int c0)
 {
-    constexpr int KP = FwdCfg<KC>::KP;
     // SUB: 240 splats per batch keep the 16 lists + records of K = 26 under 40 KB (four workgroups per CU)
     constexpr int BATCH = (SUB && KC <= 32) ? 240 : FwdCfg<KC>::BATCH;
-    __shared__ float4 s_geo[BATCH];   // x, y, A, B   (pre-scaled conic, see hsr_tile_common.h)
-    __shared__ float2 s_co[BATCH];    // C, opacity
-    __shared__ float4 s_col[BATCH];   // r, g, b, depth
-    __shared__ float s_sem[KC > 0 ? BATCH * KP : 4];
+    // per staged splat: a 32-byte record { x, y, A, B | C, opacity, r, g } (pre-scaled conic, see hsr_tile_common.h) — all the
+    // alpha test needs, in two 16-byte reads at one address — and a feature row { s0 .. s(KC-1), b, depth } whose 16-byte reads
+    // pair up with the packed FMAs (blue and depth ride in the row's padding at K = 26): one LDS read and one address
+    // computation fewer per visit than four separate arrays
+    constexpr int RW = (KC + 2 + 3) & ~3;
+    __shared__ float4 s_rec[BATCH * 2];
+    __shared__ float4 s_row[BATCH * (RW / 4)];
     __shared__ uint8_t s_list[SUB ? 1 : 4][256];
     __shared__ uint8_t s_lcnt[4][4];
     __shared__ uint8_t s_sublist[SUB ? 16 * HSR_SUB_LSTRIDE : 4];
@@ -154,16 +155,14 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
         if (t < cnt) {
             qmask = SUB ? subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0)
                         : quadrant_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
-            s_geo[t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
-            s_co[t] = make_float2((-0.5f * HSR_LOG2E) * p_co.z, p_co.w);
-            s_col[t] = make_float4(p_r, p_g, p_b, p_d);
-            if (KC > 0) {
-                float4* row = reinterpret_cast<float4*>(&s_sem[t * KP]);
+            s_rec[2 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
+            s_rec[2 * t + 1] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, p_r, p_g);
+            float rv[RW];
 #pragma unroll
-                for (int q = 0; q < KP / 4; q++)
-                    row[q] = make_float4(p_sem[4 * q], 4 * q + 1 < KC ? p_sem[4 * q + 1] : 0.f,
-                                         4 * q + 2 < KC ? p_sem[4 * q + 2] : 0.f, 4 * q + 3 < KC ? p_sem[4 * q + 3] : 0.f);
-            }
+            for (int c = 0; c < RW; c++) rv[c] = c < KC ? p_sem[c < KC ? c : 0] : (c == KC ? p_b : (c == KC + 1 ? p_d : 0.f));
+            float4* row = &s_row[t * (RW / 4)];
+#pragma unroll
+            for (int q = 0; q < RW / 4; q++) row[q] = make_float4(rv[4 * q], rv[4 * q + 1], rv[4 * q + 2], rv[4 * q + 3]);
         }
         if (SUB) publish_subblock_lists(qmask, t, s_sublist, s_subcnt);
         else publish_quadrant_lists(qmask, t, s_list, s_lcnt);
@@ -192,8 +191,9 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
                 const int j = j_next;
                 const bool valid = k < total;
                 j_next = (int)list[min(k + 1, last)];
-                const float4 g = s_geo[j];
-                const float2 co = s_co[j];
+                const float4 g = s_rec[2 * j];
+                const float4 h4 = s_rec[2 * j + 1];
+                const float2 co = make_float2(h4.x, h4.y);
                 const float dx = g.x - pfx, dy = g.y - pfy;
                 const float power2 = fmaf(co.x, dy * dy, fmaf(g.w, dx * dy, g.z * (dx * dx)));
                 const float alpha = fminf(0.99f, co.y * __builtin_amdgcn_exp2f(power2));
@@ -205,24 +205,27 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
                 }
                 if (__ballot(contrib) == 0ull) continue;
                 const float w = contrib ? alpha * T : 0.f;
-                const float4 cd = s_col[j];
                 if (BASE) {
-                    C0 = fmaf(cd.x, w, C0);
-                    C1 = fmaf(cd.y, w, C1);
-                    C2 = fmaf(cd.z, w, C2);
-                    Dd = fmaf(cd.w, w, Dd);
+                    C0 = fmaf(h4.z, w, C0);
+                    C1 = fmaf(h4.w, w, C1);
                     if (MASK) Mm += w;
-                    if (contrib && T > 0.5f && test_T < 0.5f) median_D = cd.w;
                 }
-                if (KC > 0) {
-                    const float4* row = reinterpret_cast<const float4*>(&s_sem[j * KP]);
+                {
+                    const float4* row = &s_row[j * (RW / 4)];
 #pragma unroll
-                    for (int q = 0; q < KP / 4; q++) {
+                    for (int q = 0; q < RW / 4; q++) {
                         const float4 f = row[q];
-                        if (4 * q + 0 < KC) S[4 * q + 0] = fmaf(f.x, w, S[4 * q + 0]);
-                        if (4 * q + 1 < KC) S[4 * q + 1] = fmaf(f.y, w, S[4 * q + 1]);
-                        if (4 * q + 2 < KC) S[4 * q + 2] = fmaf(f.z, w, S[4 * q + 2]);
-                        if (4 * q + 3 < KC) S[4 * q + 3] = fmaf(f.w, w, S[4 * q + 3]);
+                        const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int c = 4 * q + i;
+                            if (c < KC) S[c < KC ? c : 0] = fmaf(fv[i], w, S[c < KC ? c : 0]);
+                            else if (BASE && c == KC) C2 = fmaf(fv[i], w, C2);
+                            else if (BASE && c == KC + 1) {
+                                Dd = fmaf(fv[i], w, Dd);
+                                if (contrib && T > 0.5f && test_T < 0.5f) median_D = fv[i];
+                            }
+                        }
                     }
                 }
                 if (contrib) {
@@ -240,8 +243,9 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
             for (int k = 0; k < m; k++) {
                 const int j = j_next;   // slot fetched one iteration ahead (slot -> record are dependent LDS round trips)
                 j_next = s_list[wv][seg * 64 + min(k + 1, 63)];
-                const float4 g = s_geo[j];
-                const float2 co = s_co[j];
+                const float4 g = s_rec[2 * j];
+                const float4 h4 = s_rec[2 * j + 1];
+                const float2 co = make_float2(h4.x, h4.y);
                 const float dx = g.x - pfx, dy = g.y - pfy;
                 const float power2 = fmaf(co.x, dy * dy, fmaf(g.w, dx * dy, g.z * (dx * dx)));  // log2(G)
                 const float alpha = fminf(0.99f, co.y * __builtin_amdgcn_exp2f(power2));
@@ -253,24 +257,27 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
                 }
                 if (__ballot(contrib) == 0ull) continue;
                 const float w = contrib ? alpha * T : 0.f;
-                const float4 cd = s_col[j];
                 if (BASE) {
-                    C0 = fmaf(cd.x, w, C0);
-                    C1 = fmaf(cd.y, w, C1);
-                    C2 = fmaf(cd.z, w, C2);
-                    Dd = fmaf(cd.w, w, Dd);
+                    C0 = fmaf(h4.z, w, C0);
+                    C1 = fmaf(h4.w, w, C1);
                     if (MASK) Mm += w;
-                    if (contrib && T > 0.5f && test_T < 0.5f) median_D = cd.w;
                 }
-                if (KC > 0) {
-                    const float4* row = reinterpret_cast<const float4*>(&s_sem[j * KP]);
+                {
+                    const float4* row = &s_row[j * (RW / 4)];
 #pragma unroll
-                    for (int q = 0; q < KP / 4; q++) {
+                    for (int q = 0; q < RW / 4; q++) {
                         const float4 f = row[q];
-                        if (4 * q + 0 < KC) S[4 * q + 0] = fmaf(f.x, w, S[4 * q + 0]);
-                        if (4 * q + 1 < KC) S[4 * q + 1] = fmaf(f.y, w, S[4 * q + 1]);
-                        if (4 * q + 2 < KC) S[4 * q + 2] = fmaf(f.z, w, S[4 * q + 2]);
-                        if (4 * q + 3 < KC) S[4 * q + 3] = fmaf(f.w, w, S[4 * q + 3]);
+                        const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int c = 4 * q + i;
+                            if (c < KC) S[c < KC ? c : 0] = fmaf(fv[i], w, S[c < KC ? c : 0]);
+                            else if (BASE && c == KC) C2 = fmaf(fv[i], w, C2);
+                            else if (BASE && c == KC + 1) {
+                                Dd = fmaf(fv[i], w, Dd);
+                                if (contrib && T > 0.5f && test_T < 0.5f) median_D = fv[i];
+                            }
+                        }
                     }
                 }
                 if (contrib) {
