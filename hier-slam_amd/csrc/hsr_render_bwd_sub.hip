@@ -26,6 +26,22 @@
 #include "hsr_tile_common.h"
 #include "hsr_wave_reduce.h"
 
+#ifdef HSR_TRACE
+// Diagnostic build only (make -C hier-slam_amd/csrc trace -> libhsr_rast_trace.so, tools/trace_bwd.py): per-wave cycle counts of
+// the phases of render_bwd_sub_kernel, clock64 deltas accumulated in registers and dumped at the end.  Never in the product.
+#define HSR_TRACE_SLOTS 8
+__device__ unsigned long long g_hsr_trace_sub[16384 * HSR_TRACE_SLOTS];
+extern "C" int hsr_debug_read_trace_sub(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hsr_trace_sub), sizeof(unsigned long long) * (size_t)n);
+}
+#define TR_NOW() clock64()
+#define TR_ADD(acc, t0) (acc) += (unsigned long long)(clock64() - (t0))
+#else
+#define TR_NOW() 0ll
+#define TR_ADD(acc, t0) ((void)0)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -83,6 +99,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     const uint2 range = a.ranges[tile];
     float* panel = s_panel[wv];
     float* u7 = s_u7[wv];
+    unsigned long long tr_stage = 0, tr_loop = 0, tr_flush = 0, tr_iters = 0, tr_chunks = 0, tr_accepted = 0;
+    const long long tr_t0 = TR_NOW();
+    (void)tr_stage; (void)tr_loop; (void)tr_flush; (void)tr_iters; (void)tr_chunks; (void)tr_accepted; (void)tr_t0;
 
     // every prologue load unconditional and issued before anything consumes one (see hsr_render_bwd_mfma.hip)
     const size_t pix_ld = inside ? pix_id : 0;
@@ -134,6 +153,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
         }
     }
     const int hi_all = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    const long long tr_t1 = TR_NOW();   // end of the prologue
+    (void)tr_t1;
 
     const float bg_dot = a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2;
     const float kx = (0.5f * a.W) / HSR_LOG2E, ky = (0.5f * a.H) / HSR_LOG2E;
@@ -228,6 +249,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
+        const long long ts = TR_NOW();
+        (void)ts;
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
@@ -244,7 +267,10 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
         __syncthreads();
         load_record(hi - BATCH);
         load_id(hi - 2 * BATCH);
+        TR_ADD(tr_stage, ts);
         if (hi - cnt >= wmax) continue;   // this wave's pixels all stopped in front of this batch
+        const long long tl = TR_NOW();
+        (void)tl;
 
         const int total = build_flat_list(wv, lane, s_list, s_lcnt, s_flat);
         for (int c0 = 0; c0 < total; c0 += SB_SLOTS) {
@@ -280,7 +306,13 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 const float G = __builtin_amdgcn_exp2f(power2);
                 const float alpha = fminf(0.99f, co.y * G);
                 const bool active = valid && pos < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+#ifdef HSR_TRACE
+                tr_iters++;
+#endif
                 if (__ballot(active) == 0ull) continue;
+#ifdef HSR_TRACE
+                tr_accepted++;
+#endif
 
                 const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
                 const float test_T = T * inv_one_m_a;
@@ -312,9 +344,29 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 const float total7 = row_reduce_transpose7(v, lane);
                 if (myv_on && valid) u7[r * 32 + gq * 8 + myv] = total7;
             }
-            flush(nrows);
+            {
+                const long long tf = TR_NOW();
+                (void)tf;
+                flush(nrows);
+                TR_ADD(tr_flush, tf);
+#ifdef HSR_TRACE
+                tr_chunks++;
+#endif
+            }
+        }
+        TR_ADD(tr_loop, tl);
+    }
+#ifdef HSR_TRACE
+    if (lane == 0) {
+        const int wid = tile * 4 + wv;
+        if (wid < 16384) {
+            unsigned long long* o = g_hsr_trace_sub + (size_t)wid * HSR_TRACE_SLOTS;
+            o[0] = (unsigned long long)(clock64() - tr_t0);
+            o[1] = (unsigned long long)(tr_t1 - tr_t0);
+            o[2] = tr_stage; o[3] = tr_loop; o[4] = tr_flush; o[5] = tr_chunks; o[6] = tr_iters; o[7] = tr_accepted;
         }
     }
+#endif
 }
 
 // Geometry-only variant: the caller wants no gradient for colours, opacities or semantics (a TRACKING iteration of Hier-SLAM:

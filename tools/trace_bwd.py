@@ -12,6 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("HSR_RAST_LIB", os.path.join(ROOT, "hier-slam_amd", "libhsr_rast_trace.so"))
+os.environ["HSR_GLUE"] = "ctypes"   # the compiled glue is linked against the product library, not the trace build
 sys.path.insert(0, os.path.join(ROOT, "hier-slam_amd"))
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer_semantic, _C  # noqa: E402
 from hsr_utils.camera import replica_intrinsics, setup_camera_tensors  # noqa: E402
@@ -37,18 +38,28 @@ torch.cuda.synchronize()
 T = ((W + 15) // 16) * ((H + 15) // 16)
 n = min(T * 4, 16384) * 8
 buf = (C.c_ulonglong * n)()
-rc = _C._lib.hsr_debug_read_trace(buf, n)
+sub = os.environ.get("HSR_BWD_IMPL", "") != "mfma"   # default backward: the sub-block kernel; HSR_BWD_IMPL=mfma: the quadrant-list one
+rc = (_C._lib.hsr_debug_read_trace_sub if sub else _C._lib.hsr_debug_read_trace)(buf, n)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
 a = a[a[:, 0] > 0]
-names = ["total", "prologue", "stage+barriers", "loop(no flush)", "flush", "emit", "visits", "accepted"]
-print("waves traced:", a.shape[0], "rc", rc)
-for i, nm in enumerate(names):
-    print("%-16s mean %10.0f   p10 %10.0f   p90 %10.0f   max %10.0f" % (nm, a[:, i].mean(), np.percentile(a[:, i], 10), np.percentile(a[:, i], 90), a[:, i].max()))
 tot = a[:, 0].mean()
-print("fractions of wave time: prologue %.2f  stage %.2f  loop %.2f (of which flush %.2f, emit %.2f)" % (
-    a[:, 1].mean() / tot, a[:, 2].mean() / tot, a[:, 3].mean() / tot, a[:, 4].mean() / tot, a[:, 5].mean() / tot))
-print("cycles per visit in loop (excl. flush): %.0f ; per accepted: %.0f ; flush cycles per 16 accepted: %.0f" % (
-    (a[:, 3] - a[:, 4]).sum() / a[:, 6].sum(), (a[:, 3] - a[:, 4]).sum() / a[:, 7].sum(), 16 * a[:, 4].sum() / a[:, 7].sum()))
+print("kernel:", "render_bwd_sub_kernel" if sub else "render_bwd_mfma_kernel", " waves traced:", a.shape[0], "rc", rc)
+if sub:
+    names = ["total", "prologue", "stage+barriers", "loop(incl. flush)", "flush", "chunks", "iterations", "accepted"]
+    for i, nm in enumerate(names):
+        print("%-18s mean %10.0f   p10 %10.0f   p90 %10.0f   max %10.0f" % (nm, a[:, i].mean(), np.percentile(a[:, i], 10), np.percentile(a[:, i], 90), a[:, i].max()))
+    print("fractions of wave time: prologue %.2f  stage %.2f  loop %.2f (of which flush + emission %.2f)" % (
+        a[:, 1].mean() / tot, a[:, 2].mean() / tot, a[:, 3].mean() / tot, a[:, 4].mean() / tot))
+    print("cycles per iteration (loop excl. flush): %.0f ; flush + emission cycles per chunk: %.0f ; iterations per chunk: %.1f ; accepted %.2f" % (
+        (a[:, 3] - a[:, 4]).sum() / a[:, 6].sum(), a[:, 4].sum() / a[:, 5].sum(), a[:, 6].sum() / a[:, 5].sum(), a[:, 7].sum() / a[:, 6].sum()))
+else:
+    names = ["total", "prologue", "stage+barriers", "loop(no flush)", "flush", "emit", "visits", "accepted"]
+    for i, nm in enumerate(names):
+        print("%-16s mean %10.0f   p10 %10.0f   p90 %10.0f   max %10.0f" % (nm, a[:, i].mean(), np.percentile(a[:, i], 10), np.percentile(a[:, i], 90), a[:, i].max()))
+    print("fractions of wave time: prologue %.2f  stage %.2f  loop %.2f (of which flush %.2f, emit %.2f)" % (
+        a[:, 1].mean() / tot, a[:, 2].mean() / tot, a[:, 3].mean() / tot, a[:, 4].mean() / tot, a[:, 5].mean() / tot))
+    print("cycles per visit in loop (excl. flush): %.0f ; per accepted: %.0f ; flush cycles per 16 accepted: %.0f" % (
+        (a[:, 3] - a[:, 4]).sum() / a[:, 6].sum(), (a[:, 3] - a[:, 4]).sum() / a[:, 7].sum(), 16 * a[:, 4].sum() / a[:, 7].sum()))
 # per-tile imbalance: max over the four quadrant waves vs their mean
 tiles = a.shape[0] // 4
 q = a[: tiles * 4, 3].reshape(tiles, 4)
