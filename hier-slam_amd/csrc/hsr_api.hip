@@ -81,7 +81,9 @@ int acquire(hsr_buffer* b, size_t need, const char* what, char** out)
     return HSR_OK;
 }
 
-thread_local uint32_t* g_pinned = nullptr;
+thread_local uint32_t* g_pinned = nullptr;       // host-mapped: [0] num_rendered, [1] sequence number of the call that wrote it
+thread_local uint32_t* g_pinned_dev = nullptr;   // the device's view of it
+thread_local uint32_t g_counter_seq = 0;
 
 // ---- optional per-stage timing with HIP events (hsr_profile_*) ----
 struct StageEvents {
@@ -130,9 +132,19 @@ struct StageTimer {
 // num_rendered read-back in two steps: the copy is enqueued right behind the scan, the host waits only after it has
 // enqueued the work that does not depend on the value (an event, not a stream sync, so that work keeps the GPU busy)
 thread_local hipEvent_t g_counter_event = nullptr;
+int counter_buffer()
+{
+    if (!g_pinned) {
+        HSR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_pinned), 64, hipHostMallocDefault));
+        g_pinned[0] = g_pinned[1] = 0;
+        HSR_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_pinned_dev), g_pinned, 0));
+    }
+    return HSR_OK;
+}
 int read_counter_begin(const uint32_t* dev, hipStream_t stream)
 {
-    if (!g_pinned) HSR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_pinned), 64, hipHostMallocDefault));
+    int rc;
+    if ((rc = counter_buffer()) != HSR_OK) return rc;
     if (!g_counter_event) HSR_HIP_CHECK(hipEventCreateWithFlags(&g_counter_event, hipEventDisableTiming));
     HSR_HIP_CHECK(hipMemcpyAsync(g_pinned, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HSR_HIP_CHECK(hipEventRecord(g_counter_event, stream));
@@ -146,6 +158,31 @@ int read_counter_end(uint32_t* host_out)
     HSR_HIP_CHECK(hipEventSynchronize(g_counter_event));
     g_host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *host_out = g_pinned[0];
+    return HSR_OK;
+}
+// Direct-binning path: bin_hist_kernel's last workgroup stores {num_rendered, seq} into the host-mapped buffer itself (no copy
+// kernel, no event): the host polls the sequence number.  A launch that never completes is caught by a stream query after 10 s.
+int poll_counter(uint32_t seq, hipStream_t stream, uint32_t* host_out)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&g_pinned[1], __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xFFFu) == 0) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > 10.0) {
+                const hipError_t e = hipStreamSynchronize(stream);
+                if (e != hipSuccess || __atomic_load_n(&g_pinned[1], __ATOMIC_ACQUIRE) != seq) {
+                    hsr_set_error("num_rendered never arrived (%s)", hipGetErrorString(e));
+                    return HSR_ERR_HIP;
+                }
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    g_host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *host_out = __atomic_load_n(&g_pinned[0], __ATOMIC_RELAXED);
     return HSR_OK;
 }
 
@@ -245,16 +282,20 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     HsrBinPlan plan{0, 0};
     uint32_t* bin_scratch = reinterpret_cast<uint32_t*>(im.final_T);   // free until the render kernel writes it
     const bool binned = !force_radix && hsr_bin_plan(P, T, (size_t)W * H, &plan);
+    uint32_t seq = 0;
     if (binned) {
+        if ((rc = counter_buffer()) != HSR_OK) return rc;
+        seq = ++g_counter_seq;
+        if (seq == 0) seq = ++g_counter_seq;
         StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
-        hsr_launch_bin_count(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, stream);
+        hsr_launch_bin_count(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, stream, g_pinned_dev, seq);
     } else {
         StageTimer tm(HSR_STAGE_FWD_SCAN, stream);
         hsr_launch_scan_block_sums(P, g, stream);
     }
     HSR_LAUNCH_CHECK(in.debug, stream);
 
-    if ((rc = read_counter_begin(g.counters, stream)) != HSR_OK) return rc;
+    if (!binned && (rc = read_counter_begin(g.counters, stream)) != HSR_OK) return rc;
 
     RenderFwdArgs ra;
     ra.W = W; ra.H = H; ra.K = in.semantic ? in.K : 0; ra.semantic = in.semantic;
@@ -299,7 +340,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     }
 
     uint32_t R32 = 0;
-    if ((rc = read_counter_end(&R32)) != HSR_OK) return rc;
+    if ((rc = binned ? poll_counter(seq, stream, &R32) : read_counter_end(&R32)) != HSR_OK) return rc;
     if (R32 > 0x7fffffffu) {
         hsr_set_error("num_rendered %u overflows int", R32);
         return HSR_ERR_INVALID_ARGUMENT;
@@ -312,7 +353,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
         if (hsr_bin_resolve(ref, R32, &chk)) return R;   // the kernels found the same layout: done
         // too small after all: the speculative kernels returned at once; the render kernel's final_T (= the count table)
         // was not touched either, but recount anyway to keep this rare path independent of that
-        hsr_launch_bin_count(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, stream);
+        hsr_launch_bin_count(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, stream, g_pinned_dev, seq);
         ra.bin = BinDevRef{nullptr, nullptr, 0};
     }
 

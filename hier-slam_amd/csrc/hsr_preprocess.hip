@@ -351,7 +351,8 @@ constexpr int BIN_THREADS = 1024;     // 16 waves per workgroup: each workgroup 
                                       // out), so few large workgroups with many waves beat many small ones
 
 __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_block, const int* __restrict__ radii, int tiles_x,
-                                                               int tiles_y, GeomState g, uint32_t* __restrict__ table)
+                                                               int tiles_y, GeomState g, uint32_t* __restrict__ table,
+                                                               uint32_t* host_counter, uint32_t host_seq)
 {
     extern __shared__ uint32_t s_cnt[];   // [T]
     __shared__ uint32_t s_wsum[BIN_THREADS / 64];
@@ -410,7 +411,13 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_bl
             }
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g.counters[0] = chunk_base;   // num_rendered
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        g.counters[0] = chunk_base;   // num_rendered
+        if (host_counter) {   // straight into host-mapped memory, value first, then the call's sequence number: the host polls it
+            __hip_atomic_store(&host_counter[0], chunk_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_counter[1], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * T;
     for (int i = threadIdx.x; i < T; i += BIN_THREADS) row[i] = s_cnt[i];
@@ -546,13 +553,14 @@ bool hsr_bin_plan(int P, int T, size_t scratch_words, HsrBinPlan* plan)
 }
 
 int hsr_launch_bin_count(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, uint32_t* scratch,
-                         uint2* ranges, hipStream_t stream)
+                         uint2* ranges, hipStream_t stream, uint32_t* host_counter, uint32_t host_seq)
 {
     const int T = tiles_x * tiles_y;
     uint32_t* table = scratch;
     uint32_t* totals = table + (size_t)plan.nblk * T;
     uint32_t* base = totals + T;
-    bin_hist_kernel<<<plan.nblk, BIN_THREADS, (size_t)T * sizeof(uint32_t), stream>>>(P, plan.per_block, radii, tiles_x, tiles_y, g, table);
+    bin_hist_kernel<<<plan.nblk, BIN_THREADS, (size_t)T * sizeof(uint32_t), stream>>>(P, plan.per_block, radii, tiles_x, tiles_y, g, table,
+                                                                                     host_counter, host_seq);
     bin_scan_kernel<<<(T + BIN_SCAN_TILES - 1) / BIN_SCAN_TILES, 1024, 0, stream>>>(T, plan.nblk, table, totals);
     bin_offsets_kernel<<<1, 1024, 0, stream>>>(T, totals, base, ranges);
     return HSR_OK;
