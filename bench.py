@@ -113,14 +113,25 @@ def main():
         libc_cpu = int(_ct.CDLL(None).sched_getcpu())
         if not args.no_pin:
             full_affinity = os.sched_getaffinity(0)
-            with open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % libc_cpu) as f:
-                l3 = set()
-                for part in f.read().strip().split(","):
-                    a, _, b = part.partition("-")
-                    l3.update(range(int(a), int(b or a) + 1))
-            l3 &= full_affinity
-            if len(l3) >= 4:
-                os.sched_setaffinity(0, l3)
+
+            def l3_of(cpu):
+                with open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % cpu) as f:
+                    out = set()
+                    for part in f.read().strip().split(","):
+                        a, _, b = part.partition("-")
+                        out.update(range(int(a), int(b or a) + 1))
+                return frozenset(out & full_affinity)
+            mine = l3_of(libc_cpu)
+            lr = int(os.environ.get("LOCAL_RANK", "0"))
+            if lr:   # one L3 domain per rank: the lr-th one after the domain this rank started on
+                groups = []
+                for c in sorted(full_affinity):
+                    g = l3_of(c)
+                    if g not in groups:
+                        groups.append(g)
+                mine = groups[(groups.index(mine) + lr) % len(groups)]
+            if len(mine) >= 4:
+                os.sched_setaffinity(0, mine)
             else:
                 full_affinity = None
     except Exception:
