@@ -11,12 +11,20 @@ of the same Gaussian set and the per-Gaussian gradients are summed with one buck
 RCCL — the keyframe-parallel mapping step of SURVEY.md §8e.  value = renders of all ranks / max time.
 
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel, timed live with HIP events on the
-launch stream through the library's hsr_profile hooks) and `cpu_baseline` (the oracle on the host cores).
+launch stream through the library's hsr_profile hooks), `cpu_baseline` (the oracle on the host cores) and
+`parity` — the metric's second half, "grad max-abs-err vs ref": one more GPU step compared with the oracle
+render of the SAME workload that the cpu_baseline leg computes anyway (bit-equality of the integer state,
+image and gradient errors).
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (a child `python -m
+torch.distributed.run`, before this process has touched the GPU) and relays rank 0's line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -66,7 +74,8 @@ def perturbed_w2c(rank):
 
 
 def cpu_baseline(args, sc, cam_cpu, up):
-    """the oracle (a plain-C port of the reference's algorithm; the reference has no CPU renderer) on the host cores"""
+    """the oracle (a plain-C port of the reference's algorithm; the reference has no CPU renderer) on the host cores.
+    Returns (cpu_baseline dict, (outputs, gradients, state) of the FIRST oracle render — the parity block's expectation)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -74,18 +83,131 @@ def cpu_baseline(args, sc, cam_cpu, up):
     kw = dict(colors_precomp=sc["colors_precomp"], semantics_precomp=sc["semantics_precomp"], scales=sc["scales"],
               rotations=sc["rotations"])
     g = {n: v.numpy() for n, v in up.items()}
-    n_done, t0 = 0, time.time()
+    n_done, t0, first = 0, time.time(), None
     while True:
         out, st = O.forward(cam_cpu, sc["means3D"], sc["opacities"], threads=threads, **kw)
-        O.backward(st, cam_cpu, sc["means3D"], g, threads=threads, **kw)
-        st.free()
+        gr = O.backward(st, cam_cpu, sc["means3D"], g, threads=threads, **kw)
         n_done += 1
         el = time.time() - t0
+        if first is None:
+            first = (out, gr, st)
+        else:
+            st.free()
         if el > args.cpu_seconds or n_done >= 50:
             break
-    return {"value": n_done / el, "unit": "renders/s", "cores": threads, "kind": "port",
-            "sample": "%d fwd+bwd renders of the same %dx%d / %d Gaussians / K=%d workload by the OpenMP C oracle "
-                      "(oracle/hsr_oracle.c) on all %d host threads" % (n_done, args.width, args.height, args.P, args.K, threads)}
+    return ({"value": n_done / el, "unit": "renders/s", "cores": threads, "kind": "port",
+             "sample": "%d fwd+bwd renders of the same %dx%d / %d Gaussians / K=%d workload by the OpenMP C oracle "
+                       "(oracle/hsr_oracle.c) on all %d host threads" % (n_done, args.width, args.height, args.P, args.K, threads)},
+            first)
+
+
+def parity_block(cam_cpu, sc, up, oracle_first, dev):
+    """One more GPU step through the public API (tests/harness.run_gpu: forward, loss = sum(out * upstream), backward,
+    state read-back) against the oracle render of the same inputs.  The oracle is the checker here, never the product."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness
+    out_o, gr_o, st_o = oracle_first
+    out_g, gr_g, st_g = harness.run_gpu(cam_cpu, sc, up, semantic=True, dev=str(dev))
+    grads_o = {n: gr_o[n] for n in ("means3D", "opacities", "means2D", "scales", "rotations", "colors_precomp", "semantics_precomp")}
+    rep = harness.parity_report(out_g, gr_g, st_g, out_o, grads_o, st_o, semantic=True)
+    rep["reference"] = ("oracle/hsr_oracle.c, the builder's plain-C restatement of forward.cu / backward.cu / rasterizer_impl.cu "
+                        "— PARITY UNPINNED: the reference holds no fixtures for this path and cannot be built here (DESIGN.md §2)")
+    rep["tolerance"] = ("integers bit-exact; images and gradients 1e-4 of each tensor's largest entry (north star), and "
+                        "element-wise 1e-4 * max(|exp_i|, %g * max|exp|); n_contrib / median depth depend on exp() last-ulp "
+                        "ties at the alpha >= 1/255 and T < 0.5 thresholds and are reported as counts" % harness.FLOOR_FRAC)
+    ok_int = all(rep[k] for k in ("num_rendered_equal", "radii_equal", "tiles_touched_equal", "keys_equal", "vals_equal", "ranges_equal"))
+    rep["pass"] = bool(ok_int and max(rep["grad_err_over_max"].values()) <= 1e-4 and max(rep["image_err_over_max"].values()) <= 1e-4)
+    st_o.free()
+    return rep
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n, argv, port, python=None):
+    """the command `bench.py --gpus N` runs when no launcher started it: one rank per GPU of this node under
+    torch.distributed.run (the same line the driver uses), rendezvous on 127.0.0.1"""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    """Parent side of `python bench.py --gpus N` (N > 1, no WORLD_SIZE): nothing in this process has touched the GPU yet
+    (torch is imported, no torch.cuda call made); the ranks run in a CHILD process tree — never an exec of this one —
+    and rank 0's JSON line is relayed.  Returns the exit code."""
+    cmd = launch_command(n, argv, free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return proc.returncode if (proc.returncode or line is not None) else 1
+
+
+def parse_cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def choose_cpus(local_rank, n_local, affinity, l3_of, gpu_local_cpus=None, start_cpu=None):
+    """CPUs for one rank's process (main thread, autograd engine thread, HIP runtime threads): one L3 domain, chosen by a
+    rule that does not depend on where the launcher happened to start the process.
+
+    n_local == 1: the L3 domain of `start_cpu` (no migration).  n_local > 1: the L3 domains of the CPUs this job may use,
+    in ascending CPU order, restricted to `gpu_local_cpus[r]` (the CPUs on the NUMA node of rank r's GPU) when known;
+    the ranks that share a node take that node's domains at an even stride, so no two ranks share a domain while
+    domains last.  Returns a frozenset, or None to leave the affinity alone (fewer than 4 CPUs in the domain)."""
+    affinity = frozenset(affinity)
+    if n_local <= 1:
+        mine = frozenset(l3_of(start_cpu)) & affinity if start_cpu is not None else affinity
+        return mine if len(mine) >= 4 else None
+
+    def domains(cpus):
+        seen, out = set(), []
+        for c in sorted(cpus):
+            if c in seen:
+                continue
+            d = frozenset(l3_of(c)) & affinity
+            seen |= d
+            if d:
+                out.append(d)
+        return out
+    node_of = lambda r: frozenset(gpu_local_cpus[r]) & affinity if (gpu_local_cpus and gpu_local_cpus.get(r)) else affinity
+    mine_node = node_of(local_rank) or affinity
+    peers = [r for r in range(n_local) if (node_of(r) or affinity) == mine_node]
+    doms = domains(mine_node)
+    if not doms:
+        return None
+    pick = doms[(peers.index(local_rank) * len(doms)) // len(peers)] if len(doms) >= len(peers) else doms[peers.index(local_rank) % len(doms)]
+    return pick if len(pick) >= 4 else None
+
+
+def gpu_numa_cpus(n_local):
+    """{local rank: CPUs local to that rank's GPU} from sysfs via the device's PCI address; {} when it cannot be read"""
+    out = {}
+    try:
+        for r in range(n_local):
+            pr = torch.cuda.get_device_properties(r)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            with open("/sys/bus/pci/devices/%s/local_cpulist" % bdf) as f:
+                cpus = parse_cpulist(f.read())
+            if cpus:
+                out[r] = cpus
+    except Exception:
+        return {}
+    return out
 
 
 def main():
@@ -99,43 +221,35 @@ def main():
     ap.add_argument("--height", type=int, default=680)
     ap.add_argument("--kind", default="slam", choices=["slam", "aniso"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (also skips the parity block)")
+    ap.add_argument("--no-parity", action="store_true", help="time the oracle but do not compare the GPU step with it")
     ap.add_argument("--no-pin", action="store_true", help="leave the process free to migrate over all CPUs")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stages with HIP events")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     # Keep the process — main thread, autograd engine thread, HIP runtime threads — on the CPUs that share an L3 with the one
     # it started on (numactl-style; the full set is restored for the CPU-baseline leg).  With the threads that hand work to
     # each other under one L3 the host side of a step takes ~0.13 instead of ~0.22 ms on a 2-socket EPYC box, which is slack the
     # 0.62 ms device step needs on a busy host.
-    libc_cpu, full_affinity = -1, None
+    libc_cpu, full_affinity, pinned = -1, None, None
+    n_local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     try:
-        import ctypes as _ct
-        libc_cpu = int(_ct.CDLL(None).sched_getcpu())
+        libc_cpu = int(C.CDLL(None).sched_getcpu())
         if not args.no_pin:
             full_affinity = os.sched_getaffinity(0)
 
             def l3_of(cpu):
                 with open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % cpu) as f:
-                    out = set()
-                    for part in f.read().strip().split(","):
-                        a, _, b = part.partition("-")
-                        out.update(range(int(a), int(b or a) + 1))
-                return frozenset(out & full_affinity)
-            mine = l3_of(libc_cpu)
+                    return parse_cpulist(f.read())
             lr = int(os.environ.get("LOCAL_RANK", "0"))
-            if lr:   # one L3 domain per rank: the lr-th one after the domain this rank started on
-                groups = []
-                for c in sorted(full_affinity):
-                    g = l3_of(c)
-                    if g not in groups:
-                        groups.append(g)
-                mine = groups[(groups.index(mine) + lr) % len(groups)]
-            if len(mine) >= 4:
-                os.sched_setaffinity(0, mine)
+            pinned = choose_cpus(lr, n_local, full_affinity, l3_of, gpu_numa_cpus(n_local) if n_local > 1 else None, libc_cpu)
+            if pinned:
+                os.sched_setaffinity(0, pinned)
             else:
                 full_affinity = None
     except Exception:
-        full_affinity = None
+        full_affinity = pinned = None
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,11 +265,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it as `python bench.py --gpus %d` (it starts its "
+                         "own ranks) or under torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus, args.gpus))
+    if world > 1:
+        assert dist.get_world_size() == world and (backend != "nccl" or dist.get_backend() == "nccl")
 
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer_semantic, _C
     from hsr_utils.camera import replica_intrinsics, setup_camera_tensors
-    from hsr_utils.parallel import GradientBucket
+    from hsr_utils.parallel import PipelinedAllReduce
     from hsr_utils.synthetic import make_scene, make_upstream_grads
 
     W, H, K, P = args.width, args.height, args.K, args.P
@@ -172,9 +290,8 @@ def main():
     # summed with one bucketed all-reduce per step (76 MB at the headline sizes).  Two buckets in flight: the all-reduce of step
     # i runs on RCCL's stream while step i + 1 renders, and a bucket is waited for only when it is packed again (the timed
     # region ends with both drained).  As at N = 1 there is no optimizer inside a step.
-    buckets = [GradientBucket([leaf[n].shape for n in names], dev) for _ in range(2)] if world > 1 else None
-    works = [None, None]
-    info = {"i": 0}
+    pipe = PipelinedAllReduce([leaf[n].shape for n in names], dev, depth=2) if world > 1 else None
+    info = {}
 
     def step():
         means2D = torch.zeros(P, 3, device=dev, requires_grad=True)  # hierslam.py:895 retains this grad for densification
@@ -186,19 +303,12 @@ def main():
         for n in names:
             leaf[n].grad = None
         torch.autograd.backward([color, sem, depth, median, opac], upd)
-        if buckets is not None:
-            b = info["i"] & 1
-            info["i"] += 1
-            if works[b] is not None:
-                works[b].wait()
-            buckets[b].pack([leaf[n].grad for n in names])
-            works[b] = buckets[b].all_reduce(async_op=True)
+        if pipe is not None:
+            pipe.submit([leaf[n].grad for n in names])
 
     def sync():
-        for b in range(2):
-            if works[b] is not None:
-                works[b].wait()
-                works[b] = None
+        if pipe is not None:
+            pipe.drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -242,13 +352,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    rank_cpus = None
+    if world > 1:
+        rank_cpus = [None] * world
+        dist.all_gather_object(rank_cpus, sorted(os.sched_getaffinity(0)))
     if rank == 0:
         R = int(info["R"])
         V = int((info["radii"] > 0).sum().item())
         ms_per_step = 1e3 * elapsed / args.steps
         out = {
             "metric": "fwd+bwd renders/sec @1200x680, 500k Gaussians, 4-level tree; grad max-abs-err vs ref",
-            "value": world * args.steps / elapsed, "unit": "renders/s", "n_gpus": world, "steps": args.steps,
+            "value": world * args.steps / elapsed, "unit": "renders/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "semantic fwd+bwd render, %dx%d, P=%d %s Gaussians, K=%d semantic channels, "
@@ -279,6 +393,8 @@ def main():
                 if (wl["P"], wl["width"], wl["height"], wl["K"], wl["kind"]) == (P, W, H, K, args.kind):
                     out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"].get(dom)
                     out["roofline"]["traffic_source"] = tj["source"]
+                    if tj.get("limiter", {}).get(dom):   # what the PMC passes say bounds this kernel (the yardstick stays HBM)
+                        out["roofline"]["limiter"] = tj["limiter"][dom]
             except Exception:
                 pass
             out["stages_ms"] = {n: round(v["ms"], 4) for n, v in stages.items()}
@@ -293,10 +409,16 @@ def main():
         # device-bound; near zero while ms_per_step exceeds the device time = this box's host cannot keep the device fed
         out["host"] = {"blocked_on_device_ms_per_step": round(host_wait_ms, 4), "cpu_at_start": int(libc_cpu), "pinned_to_l3_cpus": (len(os.sched_getaffinity(0)) if full_affinity else 0),
                        "note": "ms_per_step - blocked = host-side work per step (Python glue + launches)"}
+        if rank_cpus is not None:
+            out["host"]["rank_cpus"] = rank_cpus
         if world == 1 and not args.no_cpu_baseline:
             if full_affinity:
                 os.sched_setaffinity(0, full_affinity)   # the oracle gets every host thread it is allowed
-            out["cpu_baseline"] = cpu_baseline(args, sc, cam_cpu, up)
+            out["cpu_baseline"], oracle_first = cpu_baseline(args, sc, cam_cpu, up)
+            if args.no_parity:
+                oracle_first[2].free()
+            else:
+                out["parity"] = parity_block(cam_cpu, sc, up, oracle_first, dev)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

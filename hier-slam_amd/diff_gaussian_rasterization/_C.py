@@ -294,25 +294,24 @@ def rasterize_gaussians_semantic(background, means3D, colors, semantics, opacity
     return r, color, sem, depth, median, opac, radii, g, b, i
 
 
-# Cleared by the autograd node for one call when cov3D_precomp needs no gradient (the usual case: Hier-SLAM passes scales and
-# rotations): dL_dcov3D is then neither allocated nor written, and the backward entry points return None in its place.
-want_cov3D_grad = True
-# Set by the autograd node for one call when no gradient is wanted for colours, opacities, semantics, scales, rotations, SH and
-# cov3D (a tracking iteration: only the pose is optimised): the library then forms the geometry sums only and the entry points
-# return None for the rest.
-geometry_only_grads = False
-
-
+# Two per-call options beyond the reference's argument list (keyword-only, defaults = reference behaviour; the autograd
+# node sets them from ctx.needs_input_grad — per call, so concurrent backward threads of several devices cannot see each
+# other's choice):
+#   want_cov3D_grad=False  cov3D_precomp needs no gradient (the usual case: Hier-SLAM passes scales and rotations):
+#                          dL_dcov3D is neither allocated nor written and None is returned in its place.
+#   geometry_only=True     no gradient is wanted for colours, opacities, semantics, scales, rotations, SH and cov3D (a
+#                          tracking iteration: only the pose is optimised): the library forms the geometry sums only and the
+#                          entry points return None for the rest.
 def _backward_common(semantic, background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic,
                      dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
-                     binningBuffer, imageBuffer, debug):
+                     binningBuffer, imageBuffer, debug, want_cov3D_grad=True, geometry_only=False):
     if _ext is not None and means3D.is_cuda:
         return _ext.backward_common(bool(semantic), background, means3D, radii, colors, semantics, scales, rotations,
                                     float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
                                     dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity,
                                     sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug),
-                                    bool(want_cov3D_grad), bool(geometry_only_grads),
+                                    bool(want_cov3D_grad), bool(geometry_only),
                                     torch.cuda.current_stream(means3D.device).cuda_stream)
     _require_gpu(means3D)
     dev = means3D.device
@@ -323,14 +322,14 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
     fopt = dict(dtype=torch.float32, device=dev)
     new = torch.zeros if P == 0 else torch.empty  # the library overwrites every element when P > 0
     packed_ok = P != 0 and int(_lib.hsr_backward_scratch_bytes(P, K, int(R))) > 0 and int(_lib.hsr_backward_scratch_bytes(P, K, 0)) > 0
-    geo = bool(geometry_only_grads) and packed_ok and colors is not None and colors.numel() != 0 and not _rows_or_legacy()
+    geo = bool(geometry_only) and packed_ok and colors is not None and colors.numel() != 0 and not _rows_or_legacy()
     dL_dmeans3D = new((P, 3), **fopt)
     dL_dmeans2D = new((P, 3), **fopt)
     dL_dcolors = None if geo else new((P, NUM_CHANNELS), **fopt)
     dL_dsemantics = None if geo else new((P, K), **fopt)
     # with a scratch buffer (every mode but 'legacy') dL_dconic and dL_ddepths are intermediates nobody reads (the reference
     # keeps them inside RasterizeGaussiansBackwardCUDA, rasterize_points.cu:380-383): not allocated, not written;
-    # dL_dcov3D only when the caller wants it (want_cov3D_grad, cleared by the autograd node when cov3D_precomp needs no grad)
+    # dL_dcov3D only when the caller wants it (want_cov3D_grad=False from the autograd node when cov3D_precomp needs no grad)
     packed_scratch = P != 0 and int(_lib.hsr_backward_scratch_bytes(P, K, int(R))) > 0
     dL_dconic = None if packed_scratch else new((P, 2, 2), **fopt)
     dL_ddepths = None if packed_scratch else new((P, 1), **fopt)
@@ -377,26 +376,27 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
-                                 binningBuffer, imageBuffer, debug):
+                                 binningBuffer, imageBuffer, debug, *, want_cov3D_grad=True, geometry_only=False):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:129-215) -> 8 tensors
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
     g = _backward_common(False, background, means3D, radii, colors, None, scales, rotations, scale_modifier, cov3D_precomp,
                          viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, None, dL_dout_depth,
                          dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R, binningBuffer,
-                         imageBuffer, debug)
+                         imageBuffer, debug, want_cov3D_grad, geometry_only)
     return g[0], g[1], g[3], g[4], g[5], g[6], g[7], g[8]
 
 
 def rasterize_gaussians_backward_semantic(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
                                           cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                           dL_dout_semantic, dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh,
-                                          degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                          degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, *,
+                                          want_cov3D_grad=True, geometry_only=False):
     """RasterizeGaussiansBackwardCUDA_semantic (rasterize_points.cu:340-432) -> 9 tensors
     (dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
     return _backward_common(True, background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
                             cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic,
                             dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
-                            binningBuffer, imageBuffer, debug)
+                            binningBuffer, imageBuffer, debug, want_cov3D_grad, geometry_only)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

@@ -45,13 +45,13 @@ def _snapshot(args):
     return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
 
 
-def _call(fn, args, debug, dump_name, when):
+def _call(fn, args, debug, dump_name, when, **options):
     """Runs one _C entry point; in debug mode a failure first dumps the inputs (reference :82-90, :294-301)."""
     if not debug:
-        return fn(*args)
+        return fn(*args, **options)
     saved = _snapshot(args)
     try:
-        return fn(*args)
+        return fn(*args, **options)
     except Exception:
         torch.save(saved, dump_name)
         print("\nAn error occured in %s. Please forward %s for debugging." % (when, dump_name))
@@ -101,26 +101,21 @@ class _Rasterize(torch.autograd.Function):
         head = (rs.bg, means3D, radii, colors_precomp)
         mid = (scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
                grad_color)
-        _C.want_cov3D_grad = bool(ctx.needs_input_grad[9])   # cov3Ds_precomp
-        # only means3D / means2D want a gradient (a tracking iteration optimises the camera pose alone, scripts/hierslam.py:1683-1860):
-        # the library then forms the geometry sums only — a third of the atomic traffic, no semantic upstream gradients read
-        _C.geometry_only_grads = not any(ctx.needs_input_grad[i] for i in (3, 4, 5, 6, 7, 8, 9))
-        try:
-            return _Rasterize._run_backward(ctx, rs, head, mid, tail, semantics_precomp, grad_sem, grad_depth, grad_median, grad_opacity)
-        finally:
-            _C.want_cov3D_grad = True
-            _C.geometry_only_grads = False
-
-    @staticmethod
-    def _run_backward(ctx, rs, head, mid, tail, semantics_precomp, grad_sem, grad_depth, grad_median, grad_opacity):
+        # Per-call options (arguments, not module state: autograd runs one backward thread per device):
+        #  want_cov3D_grad  cov3Ds_precomp needs a gradient;
+        #  geometry_only    only means3D / means2D want one (a tracking iteration optimises the camera pose alone,
+        #                   scripts/hierslam.py:1683-1860): the library then forms the geometry sums only — a third of the atomic
+        #                   traffic, no semantic upstream gradients read.
+        opts = dict(want_cov3D_grad=bool(ctx.needs_input_grad[9]),
+                    geometry_only=not any(ctx.needs_input_grad[i] for i in (3, 4, 5, 6, 7, 8, 9)))
         if ctx.semantic:
             args = head + (semantics_precomp,) + mid + (grad_sem, grad_depth, grad_median, grad_opacity) + tail
             (g_means2D, g_colors, g_sem, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot) = _call(
-                _C.rasterize_gaussians_backward_semantic, args, rs.debug, "snapshot_bw.dump", "backward")
+                _C.rasterize_gaussians_backward_semantic, args, rs.debug, "snapshot_bw.dump", "backward", **opts)
         else:
             args = head + mid + (grad_depth, grad_median, grad_opacity) + tail
             (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot) = _call(
-                _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+                _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward", **opts)
             g_sem = None
         # one gradient per forward input: (semantic flag, means3D, means2D, sh, colors, semantics, opacities,
         # scales, rotations, cov3Ds_precomp, settings)

@@ -35,12 +35,66 @@ class GradientBucket:
                 v.copy_(g)
 
     def all_reduce(self, group=None, average=False, async_op=False):
+        """Sum (or mean) over the ranks of `group`, in place.  async_op=True returns a handle whose wait() completes the
+        operation — the division of average=True included; None when there is nothing to exchange."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return None
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-        if average and not async_op:
-            self.flat.div_(dist.get_world_size(group))
-        return work
+        scale = 1.0 / dist.get_world_size(group) if average else None
+        if not async_op:
+            if scale is not None:
+                self.flat.mul_(scale)
+            return None
+        return _Pending(work, self.flat, scale)
+
+
+class _Pending:
+    """handle of an asynchronous bucket all-reduce: wait() blocks until the sum is in the bucket and applies the mean"""
+
+    def __init__(self, work, flat, scale):
+        self.work, self.flat, self.scale = work, flat, scale
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            if self.scale is not None:
+                self.flat.mul_(self.scale)
+            self.work = None
+
+
+class PipelinedAllReduce:
+    """`depth` gradient buckets in flight (default 2): submit() packs the gradients of step i into bucket i mod depth and
+    starts its all-reduce on the communication stream; the bucket is waited for only when it is packed again (or at drain()),
+    so the exchange of step i overlaps the render of step i + 1.  xGMI is per-link bound — a ring over the 76 MB bucket of
+    the headline workload costs about as much as a render — which is why the exchange is taken off the critical path
+    instead of being made faster.  reduced(i) returns the views of the bucket that held step i, after waiting for it."""
+
+    def __init__(self, shapes, device, depth=2, group=None, average=False, dtype=torch.float32):
+        self.buckets = [GradientBucket(shapes, device, dtype) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.group, self.average, self.step = group, average, 0
+
+    def submit(self, grads):
+        b = self.step % len(self.buckets)
+        self.step += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+        self.buckets[b].pack(grads)
+        self.pending[b] = self.buckets[b].all_reduce(group=self.group, average=self.average, async_op=True)
+        return b
+
+    def reduced(self, step):
+        b = step % len(self.buckets)
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        return self.buckets[b].views
+
+    def drain(self):
+        for b in range(len(self.buckets)):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
 
 
 def allreduce_gradients(params, group=None, average=False, bucket=None):

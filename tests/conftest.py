@@ -25,3 +25,39 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """observed HIP-vs-oracle errors of this run (tests/harness.assert_close records them): worst per tensor name,
+    printed and — on a GPU box — written to gpurun_out/parity_observed.json"""
+    try:
+        import harness
+    except Exception:
+        return
+    if not harness.OBSERVED:
+        return
+    worst = {}
+    for name, st in harness.OBSERVED:
+        w = worst.setdefault(name, dict(cases=0, err_over_max=0.0, max_abs_err=0.0, elementwise={}))
+        w["cases"] += 1
+        w["err_over_max"] = max(w["err_over_max"], st["err_over_max"])
+        w["max_abs_err"] = max(w["max_abs_err"], st["max_abs_err"])
+        for f, v in st["elementwise"].items():
+            w["elementwise"][f] = max(w["elementwise"].get(f, 0.0), v)
+    tr = terminalreporter
+    tr.write_sep("-", "observed errors vs the oracle (worst over %d comparisons; bound %.0e, element-wise floor %.2g of max)" % (
+        len(harness.OBSERVED), harness.RTOL, harness.FLOOR_FRAC))
+    for name in sorted(worst):
+        w = worst[name]
+        tr.write_line("%-28s n=%-4d err/max %.2e   element-wise at floor 1/0.1/0.01/0.001: %s" % (
+            name, w["cases"], w["err_over_max"], " ".join("%.1e" % w["elementwise"].get(f, 0.0) for f in ("1", "0.1", "0.01", "0.001"))))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        import json
+        import torch
+        if torch.cuda.is_available():
+            os.makedirs(out_dir, exist_ok=True)
+            with open(os.path.join(out_dir, "parity_observed.json"), "w") as fh:
+                json.dump(worst, fh, indent=1, sort_keys=True)
+    except Exception:
+        pass

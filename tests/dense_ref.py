@@ -177,3 +177,75 @@ def dense_loss_and_grads(cam, scene, grads, point_list, ranges, semantic=True, u
     # reference quirk (see `unit` above): dL_dopacity = true alpha-path gradient + d L / d unit
     res["opacities_ref"] = res["opacities"] + res["unit"].reshape(res["opacities"].shape)
     return out, res
+
+
+# ---- view-dependent colour from spherical harmonics (reference forward.cu:20-71, backward.cu:20-139) --------------------
+# Independent of the oracle's (and the HIP kernels') hard-coded degree-0..3 polynomials: the basis is built from the
+# general definition of the real spherical harmonics with the Condon-Shortley phase, m = -l..l inside a band,
+#     Y_lm(d) = (-1)^m sqrt(2) N_lm  [d^|m|/dz^|m| P_l](z)  Re|Im (x + i y)^|m|      (m != 0;  m = 0: N_l0 P_l(z))
+#     N_lm = sqrt((2l+1)/(4 pi) (l-|m|)!/(l+|m|)!)
+# (Legendre coefficients from numpy.polynomial; tests/test_oracle.py checks the basis against scipy.special's complex
+# harmonics.)  On the unit sphere these equal the reference's polynomials; off the sphere they differ only radially,
+# which the direction normalisation projects out of every gradient.
+def real_sh_basis(d, deg):
+    """d: [P,3] float64 unit directions -> [P,(deg+1)^2] in the reference's coefficient order."""
+    from math import factorial, pi, sqrt
+    from numpy.polynomial import legendre as L
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    cols = []
+    for l in range(deg + 1):
+        base = L.leg2poly([0.0] * l + [1.0])              # P_l as ascending power coefficients
+        for m in range(-l, l + 1):
+            a = abs(m)
+            co = np.polynomial.polynomial.polyder(base, a) if a else base
+            pz = torch.zeros_like(z)
+            for c in co[::-1]:                            # Horner
+                pz = pz * z + float(c)
+            n = sqrt((2 * l + 1) / (4 * pi) * factorial(l - a) / factorial(l + a))
+            if m == 0:
+                cols.append(n * pz)
+                continue
+            re, im = torch.ones_like(x), torch.zeros_like(x)
+            for _ in range(a):                            # (x + i y)^a
+                re, im = re * x - im * y, re * y + im * x
+            cols.append(((-1) ** a) * sqrt(2.0) * n * pz * (re if m > 0 else im))
+    return torch.stack(cols, 1)
+
+
+def sh_colors(shs, means3D, campos, deg):
+    """float64 colours [P,3] = max(sum_lm Y_lm(dir) sh_lm + 0.5, 0), dir = normalise(mean - campos)."""
+    d = means3D - campos.reshape(1, 3)
+    d = d / d.norm(dim=1, keepdim=True)
+    nb = (deg + 1) ** 2
+    Y = real_sh_basis(d, deg)
+    rgb = (Y[:, :, None] * shs[:, :nb, :]).sum(1) + 0.5
+    return torch.clamp(rgb, min=0.0)    # autograd: zero gradient where clamped (backward.cu:33-38)
+
+
+def dense_loss_and_grads_sh(cam, scene, shs, deg, grads, point_list, ranges, semantic=True):
+    """as dense_loss_and_grads with colours from SH coefficients: returns (outputs, grads incl. 'shs'; the means3D
+    gradient includes the view-direction term)."""
+    dt = torch.float64
+    tt = lambda a: torch.as_tensor(np.asarray(a)).to(dt).clone().requires_grad_(True)
+    g = (lambda k: cam[k]) if isinstance(cam, dict) else (lambda k: getattr(cam, k))
+    P = len(scene["means3D"])
+    p = dict(means3D=tt(scene["means3D"]), opacities=tt(scene["opacities"]), shs=tt(shs), scales=tt(scene["scales"]),
+             rotations=tt(scene["rotations"]),
+             semantics=tt(scene["semantics_precomp"]) if semantic else torch.zeros(P, 0, dtype=dt))
+    p["ndc_delta"] = torch.zeros(P, 2, dtype=dt, requires_grad=True)
+    p["unit"] = torch.ones(P, dtype=dt, requires_grad=True)
+    q = dict(p)
+    q["colors"] = sh_colors(p["shs"], p["means3D"], torch.as_tensor(g("campos")).to(dt).cpu(), deg)
+    out = dense_render(cam, q, point_list, ranges, semantic=semantic)
+    bg = torch.as_tensor(g("bg")).to(dt).cpu()
+    G = {k: torch.as_tensor(np.asarray(v)).to(dt) for k, v in grads.items() if v is not None}
+    Lz = (out["color"] * G["color"]).sum() + (out["depth"] * G["depth"]).sum() + (out["median"] * G["median"]).sum() \
+        + (out["opacity"] * G["opacity"]).sum() + (out["final_T"][None] * bg[:, None, None] * G["color"]).sum()
+    if semantic and out["semantic"].numel():
+        Lz = Lz + (out["semantic"] * G["semantic"]).sum()
+    leaves = {k: v for k, v in p.items() if v.requires_grad}
+    gr = torch.autograd.grad(Lz, list(leaves.values()), allow_unused=True)
+    res = {k: (gv if gv is not None else torch.zeros_like(v)) for (k, v), gv in zip(leaves.items(), gr)}
+    res["opacities_ref"] = res["opacities"] + res["unit"].reshape(res["opacities"].shape)
+    res["colors_value"] = q["colors"].detach()
+    return out, res

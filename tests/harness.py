@@ -111,12 +111,80 @@ def run_oracle(cam, sc, up, semantic=True, variant="sr", extra=None, threads=0):
     return out, grads, st
 
 
-def assert_close(name, got, exp, rtol=1e-4, atol=1e-4):
-    """|got - exp| <= atol + rtol * max|exp|  (the north-star tolerance: 1e-4 fp32)."""
+# Tolerances of the -m gpu comparisons (north star: 1e-4 fp32).  Two bounds are enforced per tensor:
+#   tensor-wide    max_i |got_i - exp_i|              <= ATOL + RTOL * max_j |exp_j|
+#   element-wise       |got_i - exp_i|                <= RTOL * max(|exp_i|, FLOOR_FRAC * max_j |exp_j|)   (+ ATOL_EL)
+# The element-wise floor exists because a gradient entry is a sum of many signed terms: its fp32 rounding error scales
+# with sum |terms|, not with the (possibly cancelled) result, so an entry of magnitude << the tensor's scale cannot be
+# held to 1e-4 of ITSELF by any fp32 implementation (the reference's own atomics included).  FLOOR_FRAC states how far
+# below the tensor's largest entry the relative bound is kept: an entry of a tenth of the tensor's maximum must still be
+# right to 1e-4 of itself; smaller entries to 1e-5 of the tensor's maximum.
+RTOL, ATOL, FLOOR_FRAC, ATOL_EL = 1e-4, 1e-4, 0.1, 1e-7
+OBSERVED = []          # (name, max abs err, max|exp|, element-wise ratio at several floors): printed by the tests' summary
+
+
+def error_stats(got, exp):
+    """observed error figures of one tensor: tensor-wide and element-wise at floors 1, 0.1, 0.01, 0.001 of max|exp|"""
+    got = np.asarray(got, np.float64)
+    exp = np.asarray(exp, np.float64).reshape(got.shape)
+    if got.size == 0:
+        return dict(max_abs_err=0.0, max_abs_exp=0.0, err_over_max=0.0, elementwise={})
+    err = np.abs(got - exp)
+    mx = float(np.abs(exp).max())
+    el = {}
+    for f in (1.0, 0.1, 0.01, 0.001):
+        el["%g" % f] = float((err / np.maximum(np.abs(exp), max(f * mx, 1e-30))).max())
+    return dict(max_abs_err=float(err.max()), max_abs_exp=mx, err_over_max=float(err.max() / mx) if mx > 0 else float(err.max()),
+                elementwise=el)
+
+
+def assert_close(name, got, exp, rtol=RTOL, atol=ATOL, floor_frac=FLOOR_FRAC, elementwise=True):
+    """tensor-wide |got - exp| <= atol + rtol * max|exp| AND element-wise |err_i| <= rtol * max(|exp_i|, floor_frac * max|exp|)."""
     got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64).reshape(np.asarray(got).shape)
     if got.size == 0:
         return 0.0
-    err = float(np.abs(got - exp).max())
-    lim = atol + rtol * float(np.abs(exp).max())
-    assert err <= lim, "%s: max abs err %.3e > %.3e (max|exp| %.3e)" % (name, err, lim, float(np.abs(exp).max()))
+    st = error_stats(got, exp)
+    OBSERVED.append((name, st))
+    err, mx = st["max_abs_err"], st["max_abs_exp"]
+    lim = atol + rtol * mx
+    assert err <= lim, "%s: max abs err %.3e > %.3e (max|exp| %.3e)" % (name, err, lim, mx)
+    if elementwise:
+        bound = rtol * np.maximum(np.abs(exp), floor_frac * mx) + ATOL_EL
+        bad = np.abs(got - exp) > bound
+        assert not bad.any(), "%s: %d of %d elements outside %.0e * max(|exp_i|, %.2g * max|exp| = %.3e); worst ratio %.3e" % (
+            name, int(bad.sum()), bad.size, rtol, floor_frac, floor_frac * mx, float((np.abs(got - exp) / bound).max()) * rtol)
     return err
+
+
+def parity_report(out_g, gr_g, st_g, out_o, gr_o, st_o, semantic=True):
+    """The comparison the bench line and the full-size tests report: integer state bit-equality, thresholded-integer
+    mismatch counts, image and gradient errors (max-abs and relative to each tensor's largest entry)."""
+    f = st_o.field
+    rep = dict(
+        num_rendered_equal=bool(st_g["num_rendered"] == out_o["num_rendered"]),
+        radii_equal=bool(np.array_equal(out_g["radii"], out_o["radii"])),
+        tiles_touched_equal=bool(np.array_equal(st_g["tiles_touched"], f("tiles_touched"))),
+        keys_equal=bool(np.array_equal(st_g["keys"], f("keys"))),
+        vals_equal=bool(np.array_equal(st_g["vals"], f("vals"))),
+        ranges_equal=bool(np.array_equal(st_g["ranges"], f("ranges"))),
+    )
+    npix = out_o["color"].shape[1] * out_o["color"].shape[2]
+    rep["n_contrib_mismatch"] = int((st_g["n_contrib"] != f("n_contrib")).sum())
+    rep["median_depth_outliers"] = int((np.abs(out_g["median_depth"] - out_o["median_depth"]) > 1e-4).sum())
+    rep["pixels"] = int(npix)
+    img, img_rel = {}, {}
+    for n in ["color", "depth", "opacity"] + (["semantic"] if semantic else ["mask"]):
+        s = error_stats(out_g[n], out_o[n])
+        img[n], img_rel[n] = s["max_abs_err"], s["err_over_max"]
+    # median depth: pixels whose crossing splat differs by a threshold tie are counted above; the rest must agree
+    md = np.abs(out_g["median_depth"] - out_o["median_depth"])
+    img["median_depth_excluding_outliers"] = float(md[md <= 1e-4].max()) if (md <= 1e-4).any() else 0.0
+    rep["image_max_abs_err"], rep["image_err_over_max"] = img, img_rel
+    ga, gr, ge = {}, {}, {}
+    for n in gr_o:
+        s = error_stats(gr_g[n], gr_o[n])
+        ga[n], gr[n], ge[n] = s["max_abs_err"], s["err_over_max"], s["elementwise"].get("%g" % FLOOR_FRAC, 0.0)
+    rep["grad_max_abs_err"], rep["grad_err_over_max"] = ga, gr
+    rep["grad_elementwise_err_floor_%g" % FLOOR_FRAC] = ge
+    rep["grad_max_abs"] = {n: float(np.abs(gr_o[n]).max()) if np.asarray(gr_o[n]).size else 0.0 for n in gr_o}
+    return rep

@@ -102,6 +102,32 @@ def test_full_size_properties(P, W, H, K):
     assert float(leaf["colors_precomp"].grad.abs().max()) == 0
 
 
+def test_headline_size_parity_vs_oracle():
+    """BASELINE.json's headline workload — 1200x680, 500k SLAM-like Gaussians, K = 26 — HIP against the oracle on the same
+    inputs: the comparison bench.py also prints in its `parity` block (tests/harness.parity_report)."""
+    import json
+    from harness import parity_report, run_oracle
+    from hsr_utils.camera import replica_intrinsics, setup_camera_tensors
+    from hsr_utils.synthetic import make_scene, make_upstream_grads
+    W, H, P, K = 1200, 680, 500000, 26
+    kmat = replica_intrinsics(W, H)
+    cam = setup_camera_tensors(W, H, kmat, np.eye(4))
+    sc = make_scene(P, W, H, K, kmat, seed=0, kind="slam")
+    up = {n: v * float(W * H) for n, v in make_upstream_grads(W, H, K, seed=1).items()}   # O(1) upstream gradients
+    out_g, gr_g, st_g = run_gpu(cam, sc, up, semantic=True)
+    out_o, gr_o, st_o = run_oracle(cam, sc, up, semantic=True)
+    rep = parity_report(out_g, gr_g, st_g, out_o, gr_o, st_o, semantic=True)
+    print("headline parity:", json.dumps(rep))
+    for k in ("num_rendered_equal", "radii_equal", "tiles_touched_equal", "keys_equal", "vals_equal", "ranges_equal"):
+        assert rep[k], k
+    assert rep["n_contrib_mismatch"] <= W * H // 2000 and rep["median_depth_outliers"] <= W * H // 2000
+    for n in ("color", "depth", "opacity", "semantic"):
+        assert_close(n, out_g[n], out_o[n])
+    for n in gr_o:
+        assert_close("grad " + n, gr_g[n], gr_o[n])
+    st_o.free()
+
+
 def test_forward_is_deterministic_and_backward_reproducible_within_fp32_noise():
     cam, sc, up = scenes.build(320, 200, 20000, 26, seed=9, kind="slam", scale_mult=2.0)
     o1, g1, s1 = run_gpu(cam, sc, up)

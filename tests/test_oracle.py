@@ -151,3 +151,148 @@ def test_golden_fixture(name):
     for n in ("means3D", "means2D", "opacities", "colors_precomp", "scales", "rotations") + (("semantics_precomp",) if semantic else ()):
         assert _rel(gr[n], z["exp_grad_" + n]) < 1e-6, n
     st.free()
+
+
+# ---- spherical-harmonics colour path: pinned independently of the oracle's polynomials ----------------
+
+def test_real_sh_basis_matches_scipy():
+    """tests/dense_ref.real_sh_basis (general definition) against scipy.special's complex harmonics, bands 0-3"""
+    from scipy import special
+    rng = np.random.default_rng(0)
+    d = rng.normal(size=(64, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    Y = DR.real_sh_basis(torch.as_tensor(d), 3).numpy()
+    theta = np.arccos(np.clip(d[:, 2], -1, 1))          # polar
+    phi = np.arctan2(d[:, 1], d[:, 0])                   # azimuth
+    harm = getattr(special, "sph_harm_y", None)
+    col = 0
+    for l in range(4):
+        for m in range(-l, l + 1):
+            a = abs(m)
+            c = harm(l, a, theta, phi) if harm is not None else special.sph_harm(a, l, phi, theta)
+            exp = c.real if m == 0 else np.sqrt(2.0) * (c.real if m > 0 else c.imag)
+            assert np.abs(Y[:, col] - exp).max() < 1e-12, (l, m)
+            col += 1
+    # and the reference's published constants (auxiliary.h:22-39) are these harmonics' leading coefficients
+    assert abs(Y[0, 0] - 0.28209479177387814) < 1e-15
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_oracle_sh_matches_float64_autograd(deg):
+    """computeColorFromSH forward (forward.cu:20-71) and backward (backward.cu:20-139) of the oracle against the
+    float64 autograd restatement built on the general harmonics; some colours are driven negative so that the clamp
+    flags and their zero gradient are exercised."""
+    W, H, K, P = 40, 36, 4, 60
+    cam, sc, up = scenes.build(W, H, P, K, seed=4, kind="aniso", scale_mult=4.0)
+    cam["sh_degree"] = deg
+    shs = scenes.random_sh(P, 16, seed=9)
+    shs[::5, 0, :] -= 3.2                       # -> negative before the clamp on every 5th Gaussian
+    shs[1::7, 0, 1] -= 3.2                      # and single channels
+    extra = {"shs": shs}
+    out, gr, st = run_oracle(cam, sc, up, semantic=True, extra=extra, threads=2)
+    g = {n: v.numpy() for n, v in up.items()}
+    dout, dgr = DR.dense_loss_and_grads_sh(cam, sc, shs.numpy(), deg, g, st.field("vals"), st.field("ranges"))
+    vis = out["radii"] > 0
+    rgb = st.field("rgb")
+    assert np.abs(rgb[vis] - dgr["colors_value"].numpy()[vis]).max() < 2e-6
+    clamped = st.field("clamped").astype(bool)
+    assert clamped[vis].any() and not clamped[vis].all()
+    assert np.array_equal(clamped[vis], (dgr["colors_value"].numpy()[vis] == 0))
+    assert np.abs(out["color"] - dout["color"].detach().numpy()).max() < 5e-6
+    nb = (deg + 1) ** 2
+    assert _rel(gr["shs"][:, :nb], dgr["shs"].numpy()[:, :nb]) < 2e-5
+    assert float(np.abs(gr["shs"][:, nb:]).max()) == 0 if nb < 16 else True
+    assert float(np.abs(gr["shs"][clamped[:, 0], :, 0]).max()) == 0   # clamped channel: no gradient (backward.cu:33-38)
+    for a, b in dict(means3D="means3D", scales="scales", rotations="rotations", opacities="opacities_ref",
+                     semantics_precomp="semantics").items():
+        assert _rel(gr[a], dgr[b].numpy()) < 2e-5, (a, _rel(gr[a], dgr[b].numpy()))
+    st.free()
+
+
+def _oracle_loss(cam, sc, up, extra=None):
+    """L = sum(outputs * upstream) in float64 from one oracle forward"""
+    kw = dict(scales=sc["scales"], rotations=sc["rotations"], semantics_precomp=sc["semantics_precomp"])
+    if extra is not None:
+        kw["shs"] = extra["shs"]
+    else:
+        kw["colors_precomp"] = sc["colors_precomp"]
+    out, st = O.forward(cam, sc["means3D"], sc["opacities"], threads=2, **kw)
+    st.free()
+    L = 0.0
+    for a, b in (("color", "color"), ("semantic", "semantic"), ("depth", "depth"), ("median_depth", "median"), ("opacity", "opacity")):
+        L += float((out[a].astype(np.float64) * up[b].numpy().astype(np.float64)).sum())
+    return L
+
+
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_oracle_gradients_match_finite_differences(use_sh):
+    """Central differences of the oracle's OWN forward against its analytic backward — no second derivation involved.
+
+    What such a check can and cannot show.  The reference's backward is not the derivative of its forward in five places;
+    four are switched off here: Gaussians outside 0.9 x the 1.3 tan(fov) frustum clamp are left out (the clamped
+    coordinate gets gradient 0 by decree, backward.cu:175-176, while the forward does move with it), final opacity's upstream is 0 (its colour-style term is added to dL_dopacity,
+    backward.cu:859-864), bg = 0 (the forward never composites it, forward.cu:530-531), the semantic upstream is 0 except
+    when dL_dsemantics itself is checked (the semantic loss never reaches alpha, backward.cu:834), and median depth
+    (piecewise constant) gets upstream 0.  The fifth cannot be switched off: the analytic gradient treats the support of a
+    splat (alpha >= 1/255) as fixed, while a finite difference sees the rim move — for a splat of opacity o that is a
+    systematic (2 ln(255 o)/255)/(2 o) of the main term, 2-3 % at o > 0.8 — so the geometric parameters are compared at
+    3 % of the tensor's largest gradient on a scene of opaque splats and smooth upstream fields (white-noise upstreams
+    turn every rim pixel into a +-|up|/255/h jump); colours, SH coefficients and semantics enter linearly and are compared
+    at 2e-3."""
+    W, H, K, P = 40, 36, 4, 50
+    cam, sc, up = scenes.build(W, H, P, K, seed=6, kind="aniso", scale_mult=5.0)
+    sc["opacities"] = (0.8 + 0.19 * torch.rand(P, 1, generator=torch.Generator().manual_seed(2))).float()
+    extra = None
+    if use_sh:
+        cam["sh_degree"] = 3
+        extra = {"shs": scenes.random_sh(P, 16, seed=3)}
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    smooth = lambda a, b, c: (a + b * xx + c * yy + 0.5 * xx * yy).float()[None].contiguous()
+    up = dict(color=torch.cat([smooth(0.6, 0.5, -0.3), smooth(-0.4, 0.2, 0.6), smooth(0.3, -0.6, 0.2)]).contiguous(),
+              semantic=torch.zeros(K, H, W), depth=smooth(0.2, -0.3, 0.4), median=torch.zeros(1, H, W),
+              opacity=torch.zeros(1, H, W))
+    up_sem = torch.cat([smooth(0.1 * k, 0.3, -0.2 * k) for k in range(K)]).contiguous()
+    _, gr, st = run_oracle(cam, sc, up, semantic=True, extra=extra, threads=2)
+    st.free()
+    rng = np.random.default_rng(1)
+    t = torch.cat([sc["means3D"], torch.ones(P, 1)], 1) @ cam["viewmatrix"].reshape(4, 4)
+    inside = ((t[:, 0] / t[:, 2]).abs() < 0.9 * 1.3 * cam["tanfovx"]) & ((t[:, 1] / t[:, 2]).abs() < 0.9 * 1.3 * cam["tanfovy"])
+    inside = inside.numpy()
+    assert 10 < inside.sum() < P
+    params = [("means3D", sc["means3D"], 0.03), ("scales", sc["scales"], 0.03), ("rotations", sc["rotations"], 0.03),
+              ("opacities", sc["opacities"], 0.03)]
+    params.append(("shs", extra["shs"], 2e-3) if use_sh else ("colors_precomp", sc["colors_precomp"], 2e-3))
+    checked, worst = 0, {}
+    for name, tens, tol in params:
+        ga = gr[name].reshape(tens.shape)
+        scale = float(np.abs(ga[inside]).max())
+        gsel = np.where(inside.reshape((-1,) + (1,) * (ga.ndim - 1)), np.abs(ga), 0.0)
+        flat = np.argsort(-gsel.reshape(-1))[:40]                # entries with a large analytic gradient
+        for idx in rng.choice(flat, size=6, replace=False):
+            ix = tuple(int(i) for i in np.unravel_index(int(idx), tens.shape))
+            x0 = float(tens[ix])
+            h = (0.25 if tol < 1e-2 else 4e-3 * max(abs(x0), 0.05))
+            tens[ix] = x0 + h; Lp = _oracle_loss(cam, sc, up, extra)
+            tens[ix] = x0 - h; Lm = _oracle_loss(cam, sc, up, extra)
+            tens[ix] = x0
+            fd = (Lp - Lm) / (2 * h)
+            worst[name] = max(worst.get(name, 0.0), abs(fd - float(ga[ix])) / scale)
+            assert abs(fd - float(ga[ix])) <= tol * scale + 1e-6, (name, ix, fd, float(ga[ix]), scale)
+            checked += 1
+    # dL_dsemantics: linear in the semantics, exact up to rounding
+    up["semantic"] = up_sem
+    _, gr, st = run_oracle(cam, sc, up, semantic=True, extra=extra, threads=2)
+    st.free()
+    ga = gr["semantics_precomp"]
+    for idx in rng.choice(np.argsort(-np.abs(ga).reshape(-1))[:40], size=6, replace=False):
+        ix = tuple(int(i) for i in np.unravel_index(int(idx), ga.shape))
+        x0 = float(sc["semantics_precomp"][ix])
+        sc["semantics_precomp"][ix] = x0 + 0.25; Lp = _oracle_loss(cam, sc, up, extra)
+        sc["semantics_precomp"][ix] = x0 - 0.25; Lm = _oracle_loss(cam, sc, up, extra)
+        sc["semantics_precomp"][ix] = x0
+        e = abs((Lp - Lm) / 0.5 - float(ga[ix])) / float(np.abs(ga).max())
+        worst["semantics"] = max(worst.get("semantics", 0.0), e)
+        assert e <= 2e-3, ("semantics", ix)
+        checked += 1
+    print("finite differences, worst |fd - analytic| / max|analytic|:", {k: "%.2e" % v for k, v in worst.items()})
+    assert checked == 36

@@ -48,6 +48,30 @@ def _worker(rank, world, port, q):
         p.grad = g.clone()
     allreduce_gradients(params, bucket=bucket)
     assert shard_keyframes(range(5), rank, world) == list(range(5))[rank::world]
+    # the bench's double-buffered exchange (bench.py step()): the all-reduce of step i is waited for only when its bucket is
+    # packed again; every step's reduced gradients must equal the serial sum over ranks, and nothing may be left in flight
+    from hsr_utils.parallel import PipelinedAllReduce
+    pipe = PipelinedAllReduce([g.shape for g in grads], "cpu", depth=2)
+    seen = {}
+    for i in range(5):
+        if i >= 2:   # bucket i % 2 is about to be reused: what it held (step i - 2) is read first
+            seen[i - 2] = [v.clone() for v in pipe.reduced(i - 2)]
+        pipe.submit([g * float(i + 1) for g in grads])
+    for i in (3, 4):
+        seen[i] = [v.clone() for v in pipe.reduced(i)]
+    pipe.drain()
+    assert all(w is None for w in pipe.pending)
+    for i, vs in seen.items():
+        for v, g in zip(vs, grads):
+            tot = g.clone() * float(i + 1)
+            dist.all_reduce(tot)          # the serial (blocking) sum of the same per-rank gradients
+            assert torch.equal(v, tot), "pipelined bucket of step %d differs from the serial sum" % i
+    # mean + asynchronous: the division happens in wait() (it used to be dropped silently)
+    b = GradientBucket([(3,)], "cpu")
+    b.pack([torch.full((3,), float(rank + 1))])
+    h = b.all_reduce(average=True, async_op=True)
+    h.wait()
+    assert torch.allclose(b.flat, torch.full((3,), sum(range(1, world + 1)) / world))
     if rank == 0:
         q.put([p.grad.numpy() for p in params])
     dist.barrier()
@@ -81,3 +105,60 @@ def test_bucket_single_process_noop():
     b.pack([torch.ones(4, 3), None])
     assert b.all_reduce() is None and float(b.flat.sum()) == 12.0
     assert b.views[0].shape == (4, 3) and b.views[1].shape == (4, 1)
+
+
+def _bench():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_bench_launch_command():
+    """`python bench.py --gpus N` without a launcher starts N ranks under torch.distributed.run"""
+    bench = _bench()
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "7"], 29999, python="py")
+    assert cmd[:3] == ["py", "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7"]
+    assert 1024 < bench.free_port() < 65536
+
+
+def test_bench_self_launch_relays_rank0_line(monkeypatch, capsys):
+    """the parent relays the child's JSON line on stdout, everything else on stderr, and returns the child's exit code —
+    and never calls into torch.cuda (it must stay GPU-free so that the ranks are plain children)"""
+    bench = _bench()
+    import torch.cuda
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("parent touched the GPU")))
+    child = "print('noise'); print('{\"metric\": \"m\", \"n_gpus\": 2}')"
+    monkeypatch.setattr(bench, "launch_command", lambda n, argv, port, python=None: [sys.executable, "-c", child])
+    assert bench.self_launch(2, ["--gpus", "2"]) == 0
+    cap = capsys.readouterr()
+    assert cap.out.strip() == '{"metric": "m", "n_gpus": 2}' and "noise" in cap.err
+    monkeypatch.setattr(bench, "launch_command", lambda n, argv, port, python=None: [sys.executable, "-c", "import sys; sys.exit(3)"])
+    assert bench.self_launch(2, []) == 3
+    monkeypatch.setattr(bench, "launch_command", lambda n, argv, port, python=None: [sys.executable, "-c", "pass"])
+    assert bench.self_launch(2, []) == 1      # no line: a failure even if the child exited 0
+
+
+def test_bench_rank_cpu_sets_do_not_collide():
+    """each rank gets its own L3 domain on its GPU's NUMA node, whatever CPU the launcher started it on"""
+    bench = _bench()
+    l3 = lambda c: set(range((c // 8) * 8, (c // 8) * 8 + 8))
+    numa = {r: set(range(0, 64)) if r < 4 else set(range(64, 128)) for r in range(8)}
+    picks = [bench.choose_cpus(r, 8, range(128), l3, numa, start_cpu=(r * 37) % 128) for r in range(8)]
+    assert all(len(p) == 8 for p in picks)
+    assert len(set(picks)) == 8
+    for r, p in enumerate(picks):
+        assert p <= numa[r]
+    # same answer wherever the rank started
+    assert picks == [bench.choose_cpus(r, 8, range(128), l3, numa, start_cpu=5) for r in range(8)]
+    # unknown NUMA layout: still disjoint; more ranks than domains: wraps instead of failing
+    assert len(set(bench.choose_cpus(r, 8, range(128), l3, None) for r in range(8))) == 8
+    assert bench.choose_cpus(3, 4, range(16), l3, None) in (frozenset(range(0, 8)), frozenset(range(8, 16)))
+    # one rank: the L3 of the CPU it runs on; tiny domains: leave the affinity alone
+    assert bench.choose_cpus(0, 1, range(128), l3, None, start_cpu=13) == frozenset(range(8, 16))
+    assert bench.choose_cpus(0, 1, range(128), lambda c: {c}, None, start_cpu=13) is None
+    assert bench.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
