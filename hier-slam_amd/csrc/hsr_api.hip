@@ -11,6 +11,7 @@
 #include <stdarg.h>
 
 #include <chrono>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,14 +46,17 @@ uint32_t higher_msb(uint32_t n)  // reference getHigherMsb, rasterizer_impl.cu:3
     return msb;
 }
 
-// backward accumulation mode: 0 packed per-Gaussian rows (default), 1 per-instance rows (experimental),
-// 2 legacy separate arrays.  Initialised from HSR_BWD_IMPL=rows|legacy, changed with hsr_set_backward_mode().
+// backward accumulation mode: 0 packed per-Gaussian rows (default), 1 per-instance rows (experiment: ablate build only),
+// 2 legacy separate arrays.  Initialised from HSR_BWD_IMPL=legacy (rows: ablate build), changed with hsr_set_backward_mode().
 int g_bwd_mode = -1;
 int backward_mode()
 {
     if (g_bwd_mode < 0) {
         const char* e = getenv("HSR_BWD_IMPL");
-        g_bwd_mode = (e && !strcmp(e, "rows")) ? 1 : (e && !strcmp(e, "legacy")) ? 2 : 0;
+        g_bwd_mode = (e && !strcmp(e, "legacy")) ? 2 : 0;
+#ifdef HSR_ABLATE
+        if (e && !strcmp(e, "rows")) g_bwd_mode = 1;
+#endif
     }
     return g_bwd_mode;
 }
@@ -81,9 +85,29 @@ int acquire(hsr_buffer* b, size_t need, const char* what, char** out)
     return HSR_OK;
 }
 
-thread_local uint32_t* g_pinned = nullptr;       // host-mapped: [0] num_rendered, [1] sequence number of the call that wrote it
-thread_local uint32_t* g_pinned_dev = nullptr;   // the device's view of it
-thread_local uint32_t g_counter_seq = 0;
+// Host-mapped read-back slot of the calling thread for ONE device: [0] num_rendered, [1] sequence number of the call that
+// wrote it, [2] prefilter-violation flag.  One slot per (thread, device): a thread that renders on two devices gets two,
+// each allocated (portable + mapped) while its device is current; freed when the thread ends (thread-local destructors of
+// the main thread run at the start of exit(), before the HIP runtime's own teardown).
+struct PinnedCounter {
+    uint32_t* host = nullptr;
+    uint32_t* dev = nullptr;   // the device's view of it
+    uint32_t seq = 0;
+    hipEvent_t event = nullptr;
+    double wait_ema_us = 0.0;   // how long the host recently waited for the count: sizes the sleep in front of the poll
+    ~PinnedCounter()
+    {
+        if (event) (void)hipEventDestroy(event);
+        if (host) (void)hipHostFree(host);
+    }
+};
+constexpr int HSR_MAX_DEVICES = 64;
+thread_local PinnedCounter g_counters_by_device[HSR_MAX_DEVICES];
+thread_local PinnedCounter* g_pc = nullptr;      // the current call's slot (set by counter_buffer())
+#define g_pinned (g_pc->host)
+#define g_pinned_dev (g_pc->dev)
+#define g_counter_seq (g_pc->seq)
+#define g_counter_event (g_pc->event)
 
 // ---- optional per-stage timing with HIP events (hsr_profile_*) ----
 struct StageEvents {
@@ -131,12 +155,18 @@ struct StageTimer {
 
 // num_rendered read-back in two steps: the copy is enqueued right behind the scan, the host waits only after it has
 // enqueued the work that does not depend on the value (an event, not a stream sync, so that work keeps the GPU busy)
-thread_local hipEvent_t g_counter_event = nullptr;
 int counter_buffer()
 {
+    int d = 0;
+    HSR_HIP_CHECK(hipGetDevice(&d));
+    if (d < 0 || d >= HSR_MAX_DEVICES) {
+        hsr_set_error("device index %d out of range", d);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    g_pc = &g_counters_by_device[d];
     if (!g_pinned) {
-        HSR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_pinned), 64, hipHostMallocDefault));
-        g_pinned[0] = g_pinned[1] = 0;
+        HSR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_pinned), 64, hipHostMallocPortable | hipHostMallocMapped));
+        g_pinned[0] = g_pinned[1] = g_pinned[2] = 0;
         HSR_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_pinned_dev), g_pinned, 0));
     }
     return HSR_OK;
@@ -147,6 +177,7 @@ int read_counter_begin(const uint32_t* dev, hipStream_t stream)
     if ((rc = counter_buffer()) != HSR_OK) return rc;
     if (!g_counter_event) HSR_HIP_CHECK(hipEventCreateWithFlags(&g_counter_event, hipEventDisableTiming));
     HSR_HIP_CHECK(hipMemcpyAsync(g_pinned, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HSR_HIP_CHECK(hipMemcpyAsync(g_pinned + 2, dev + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));   // prefilter flag
     HSR_HIP_CHECK(hipEventRecord(g_counter_event, stream));
     return HSR_OK;
 }
@@ -165,6 +196,15 @@ int read_counter_end(uint32_t* host_out)
 int poll_counter(uint32_t seq, hipStream_t stream, uint32_t* host_out)
 {
     const auto t0 = std::chrono::steady_clock::now();
+    // Back-off: the count arrives when the kernels queued in front of it (typically the previous step's backward) have run —
+    // a few hundred microseconds in a training loop — and a `pause` loop would hold a core at 100 % for all of it.  Sleep
+    // through the first half of the recently observed wait (an average over the last calls), then poll; short waits (< 0.15
+    // ms: the count is already there or nearly) are polled from the start.
+    if (g_pc->wait_ema_us > 150.0 && __atomic_load_n(&g_pinned[1], __ATOMIC_ACQUIRE) != seq) {
+        timespec ts{0, (long)(g_pc->wait_ema_us * 0.5 * 1000.0)};
+        if (ts.tv_nsec > 2000000L) ts.tv_nsec = 2000000L;
+        nanosleep(&ts, nullptr);
+    }
     unsigned spins = 0;
     while (__atomic_load_n(&g_pinned[1], __ATOMIC_ACQUIRE) != seq) {
         if ((++spins & 0xFFFu) == 0) {
@@ -181,7 +221,9 @@ int poll_counter(uint32_t seq, hipStream_t stream, uint32_t* host_out)
         __builtin_ia32_pause();
 #endif
     }
-    g_host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double waited_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g_host_wait_ms += waited_ms;
+    g_pc->wait_ema_us = 0.75 * g_pc->wait_ema_us + 0.25 * waited_ms * 1000.0;
     *host_out = __atomic_load_n(&g_pinned[0], __ATOMIC_RELAXED);
     return HSR_OK;
 }
@@ -268,6 +310,8 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
 
     {
         StageTimer tm(HSR_STAGE_FWD_PREPROCESS, stream);
+        // counters[1]: set by preprocess_kernel when prefiltered is on and a point fails the frustum test
+        if (in.prefiltered) HSR_HIP_CHECK(hipMemsetAsync(g.counters + 1, 0, sizeof(uint32_t), stream));
         hsr_launch_preprocess(pa, g, stream);
     }
     HSR_LAUNCH_CHECK(in.debug, stream);
@@ -302,7 +346,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     ra.ranges = im.ranges; ra.point_list = nullptr; ra.means2D = g.means2D; ra.conic_opacity = g.conic_opacity;
     ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb; ra.semantics = in.semantics;
     ra.rec = g.rec;
-    ra.final_T = im.final_T; ra.n_contrib = im.n_contrib;
+    ra.final_T = im.final_T; ra.n_contrib = im.n_contrib; ra.median_pos = im.median_pos;
     ra.out_color = in.out_color; ra.out_semantic = in.out_semantic; ra.out_depth = in.out_depth;
     ra.out_median_depth = in.out_median; ra.out_opacity = in.out_opacity; ra.out_mask = in.out_mask; ra.debug_flags = 0;
     ra.bin = BinDevRef{nullptr, nullptr, 0};
@@ -317,7 +361,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     // The host then waits on an event that completed long ago instead of idling the stream while it wakes up and launches
     // the rest — the reference stalls here on every frame (rasterizer_impl.cu:285), and with a 0.65 ms render the host
     // side (~0.45 ms per fwd+bwd through Python) would otherwise be on the critical path.
-    static const bool no_speculation = getenv("HSR_NO_SPECULATION") != nullptr;
+    static const bool no_speculation = hsr_ablate_env("HSR_NO_SPECULATION") != nullptr;
     bool speculated = false;
     if (binned && !no_speculation && !in.debug && binning && binning->ptr && binning->capacity >= 4096) {
         const BinDevRef ref{static_cast<char*>(binning->ptr), reinterpret_cast<const uint32_t*>(g.counters), binning->capacity};
@@ -346,6 +390,11 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
         return HSR_ERR_INVALID_ARGUMENT;
     }
     const int R = (int)R32;
+    if (in.prefiltered && __atomic_load_n(&g_pinned[2], __ATOMIC_RELAXED) != 0) {
+        // the reference's device-side message and __trap() (auxiliary.h:156-160), as an error return instead of a dead queue
+        hsr_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
     if (speculated) {
         BinState chk;
         const BinDevRef ref{static_cast<char*>(binning->ptr), nullptr, binning->capacity};
@@ -479,9 +528,13 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     //       the per-Gaussian kernel — half the atomic requests of the reference's six separate arrays;
     //   rows (HSR_BWD_IMPL=rows, K <= 27): per-instance rows, no global atomics (experimental);
     //   legacy (no scratch): atomics straight into the six output arrays.
+#ifdef HSR_ABLATE
     const bool want_rows = rows_mode_requested();
     const bool use_rows = want_rows && in.scratch && hsr_rows_supported(K) && in.R > 0 &&
                           in.scratch_bytes >= hsr_backward_scratch_bytes(P, K, in.R);
+#else
+    const bool use_rows = false;
+#endif
     int gstride = hsr_grow_stride(K);
     const bool use_packed = !use_rows && backward_mode() != 2 && in.scratch &&
                             in.scratch_bytes >= (size_t)P * gstride * sizeof(float) + 256;
@@ -498,6 +551,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     int rows_kc = 0;
     float* rows = nullptr;
     uint32_t* inv = nullptr;
+#ifdef HSR_ABLATE
     if (use_rows) {
         char* sp = in.scratch;
         take(sp, rows, (size_t)in.R * (size_t)hsr_rows_row_floats(K));
@@ -505,7 +559,9 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         // SH coefficients above the active degree (and those of culled Gaussians) receive no gradient
         if (!in.colors_precomp && in.shs && in.dL_dsh && in.M > 0)
             HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsh, 0, sizeof(float) * 3 * (size_t)in.M * (size_t)P, stream));
-    } else if (use_packed) {
+    } else
+#endif
+    if (use_packed) {
         if (geo) gstride = 16;   // one 64-byte line per Gaussian: columns 0..6
         char* sp = in.scratch;
         take(sp, grow, (size_t)P * gstride);
@@ -521,13 +577,13 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         RenderBwdArgs ra;
         ra.W = W; ra.H = H; ra.K = K; ra.semantic = in.semantic; ra.P = P;
         {
-            static const int dbg = getenv("HSR_DEBUG_FLAGS") ? atoi(getenv("HSR_DEBUG_FLAGS")) : 0;
-            ra.debug_flags = dbg;
+            static const int dbg = hsr_ablate_env("HSR_DEBUG_FLAGS") ? atoi(hsr_ablate_env("HSR_DEBUG_FLAGS")) : 0;
+            ra.debug_flags = dbg;   // 0 in the product build
         }
         ra.bg = in.background; ra.ranges = im.ranges; ra.point_list = b.vals; ra.means2D = g.means2D;
         ra.conic_opacity = g.conic_opacity; ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb;
         ra.rec = g.rec;
-        ra.final_T = im.final_T; ra.n_contrib = im.n_contrib;
+        ra.final_T = im.final_T; ra.n_contrib = im.n_contrib; ra.median_pos = im.median_pos;
         ra.dL_dpix = in.dL_dpix; ra.dL_dpix_sem = in.dL_dpix_sem; ra.dL_dpix_depth = in.dL_dpix_depth;
         ra.dL_dpix_median = in.dL_dpix_median; ra.dL_dpix_opacity = in.dL_dpix_opacity;
         ra.dL_dmean2D = in.dL_dmean2D; ra.dL_dconic = in.dL_dconic; ra.dL_dopacity = in.dL_dopacity;
@@ -536,11 +592,14 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         ra.grow = grow;
         ra.grow_stride = gstride;
         StageTimer tm(HSR_STAGE_BWD_RENDER, stream);
+#ifdef HSR_ABLATE
         if (use_rows) {
             const int tiles_x = (W + HSR_TILE_X - 1) / HSR_TILE_X, tiles_y = (H + HSR_TILE_Y - 1) / HSR_TILE_Y;
             hsr_launch_inverse_map(in.R, tiles_x, tiles_y, b.keys, b.vals, g.means2D, radii, g.point_offsets, inv, stream);
             rows_kc = hsr_launch_render_backward_rows(ra, stream);
-        } else if (geo) {
+        } else
+#endif
+        if (geo) {
             hsr_launch_render_backward_geo(ra, stream);
         } else {
             hsr_launch_render_backward(ra, stream);
@@ -613,6 +672,7 @@ size_t hsr_carve_img(char* base, int W, int H, ImgState* out)
     take(p, s.ranges, T);
     take(p, s.final_T, N);
     take(p, s.n_contrib, N);
+    take(p, s.median_pos, N);
     if (out) *out = s;
     return (size_t)(p - base);
 }
@@ -638,8 +698,10 @@ size_t hsr_required_binning_bytes(int num_rendered) { return hsr_carve_bin(nullp
 size_t hsr_backward_scratch_bytes(int P, int K, int num_rendered)
 {
     if (P <= 0 || K < 0 || backward_mode() == 2) return 0;
+#ifdef HSR_ABLATE
     if (rows_mode_requested() && hsr_rows_supported(K) && num_rendered > 0)
         return (size_t)num_rendered * ((size_t)hsr_rows_row_floats(K) * 4 + 4) + 1024;
+#endif
     return (size_t)P * hsr_grow_stride(K) * sizeof(float) + 512;  // packed per-Gaussian rows
 }
 
@@ -653,6 +715,12 @@ int hsr_set_backward_mode(int mode)
         hsr_set_error("backward mode must be 0 (packed), 1 (rows) or 2 (legacy)");
         return HSR_ERR_INVALID_ARGUMENT;
     }
+#ifndef HSR_ABLATE
+    if (mode == 1) {
+        hsr_set_error("the per-instance rows mode is an experiment (measured slower): it exists in the ablate build only");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+#endif
     g_bwd_mode = mode;
     return HSR_OK;
 }
@@ -720,6 +788,7 @@ int hsr_get_state_layout(int P, int width, int height, int num_rendered, hsr_sta
     out->bin_keys_unsorted = OFF(b.keys_unsorted); out->bin_keys = OFF(b.keys); out->bin_vals_unsorted = OFF(b.vals_unsorted);
     out->bin_vals = OFF(b.vals);
     out->img_ranges = OFF(im.ranges); out->img_final_T = OFF(im.final_T); out->img_n_contrib = OFF(im.n_contrib);
+    out->img_median_pos = OFF(im.median_pos);
 #undef OFF
     return HSR_OK;
 }

@@ -108,7 +108,7 @@ __device__ void sh_backward(int idx, int deg, int max_coeffs, float mx, float my
 }
 
 // KC < 0: legacy mode (sums already accumulated atomically in dL_dmean2D / dL_dconic / dL_ddepth).
-// KC >= 0: rows mode — this thread first sums the rows of its Gaussian's instances (emission order = ascending
+// KC >= 0 (ablate build only): rows mode — this thread first sums the rows of its Gaussian's instances (emission order = ascending
 // tile id inside its rect, a FIXED order: gradients are bit-reproducible), writes the six per-Gaussian sums
 // the tile kernel used to add atomically, and continues with them in registers.
 template <int KC>
@@ -325,10 +325,12 @@ int hsr_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t stream)
     const dim3 grid((a.P + 255) / 256), block(256);
     switch (a.rows_kc) {
     case 0: preprocess_backward_kernel<-1><<<grid, block, 0, stream>>>(a); break;
+#ifdef HSR_ABLATE   // per-instance rows experiment (experiments/hsr_render_bwd_rows.hip)
     case 11: preprocess_backward_kernel<11><<<grid, block, 0, stream>>>(a); break;
     case 16: preprocess_backward_kernel<16><<<grid, block, 0, stream>>>(a); break;
     case 26: preprocess_backward_kernel<26><<<grid, block, 0, stream>>>(a); break;
     case 27: preprocess_backward_kernel<27><<<grid, block, 0, stream>>>(a); break;
+#endif
     default: hsr_set_error("unsupported rows_kc %d", a.rows_kc); return HSR_ERR_INVALID_ARGUMENT;
     }
     return HSR_OK;

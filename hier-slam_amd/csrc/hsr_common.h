@@ -32,6 +32,11 @@ struct ImgState {
     uint2* ranges;        // [T]
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
+    uint32_t* median_pos; // [N] 1 + list position of the splat at which the pixel's T crossed 0.5 in the forward (0: it never did).
+                          //     The reference's backward re-finds that splat from the T it reconstructs by division
+                          //     (backward.cu:623-626, :854-857), which is exact only up to rounding: on a pixel whose T passes
+                          //     within an ulp of 0.5 it picks a neighbour, none or two.  Recording the forward's own decision
+                          //     makes the median-depth gradient land on exactly the splat whose depth the forward output.
 };
 struct BinState {
     uint64_t* keys_unsorted;  // [R]
@@ -74,6 +79,19 @@ size_t hsr_carve_bin(char* base, int R, BinState* out);
 uint32_t hsr_sort_hist_entries(int R);
 
 void hsr_set_error(const char* fmt, ...);
+
+// Ablation switches (HSR_DEBUG_FLAGS, HSR_FWD_DEBUG, HSR_NO_SPECULATION) and the measured-slower experimental kernel
+// families (csrc/experiments/: moments backward, per-instance rows backward, pair-pipelined forward) exist only in the
+// diagnostic build (`make ablate` -> libhsr_rast_ablate.so, -DHSR_ABLATE).  The product library reads none of them: a
+// stray environment variable cannot change its results.  What the product still reads are the parity-tested kernel-family
+// selectors HSR_FWD_IMPL=valu, HSR_BWD_IMPL=valu|mfma|legacy and HSR_SORT_IMPL=radix|block (every choice gives the same
+// results; tests/test_gpu_golden_and_scale.py runs the parity cases under each).
+#ifdef HSR_ABLATE
+#include <stdlib.h>
+static inline const char* hsr_ablate_env(const char* name) { return getenv(name); }
+#else
+static inline const char* hsr_ablate_env(const char*) { return nullptr; }
+#endif
 
 #define HSR_HIP_CHECK(expr)                                                                     \
     do {                                                                                        \
@@ -145,6 +163,7 @@ struct RenderFwdArgs {
     const float* semantics;  // [P,K] or NULL
     float* final_T;
     uint32_t* n_contrib;
+    uint32_t* median_pos;
     float* out_color;
     float* out_semantic;
     float* out_depth;
@@ -171,6 +190,7 @@ struct RenderBwdArgs {
     const float4* rec;    // packed per-Gaussian record (GeomState::rec), or NULL
     const float* final_T;
     const uint32_t* n_contrib;
+    const uint32_t* median_pos;
     const float* dL_dpix;
     const float* dL_dpix_sem;
     const float* dL_dpix_depth;

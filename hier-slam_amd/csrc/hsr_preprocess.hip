@@ -128,7 +128,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessArgs a, GeomS
             const float tvy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
             const float tvz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
             if (tvz <= 0.2f) {
-                if (a.prefiltered) __builtin_trap();  // reference traps too (auxiliary.h:156-160)
+                // The reference traps the device here (auxiliary.h:156-160).  A trap is a queue exception on ROCm — it takes
+                // the process (and the host's wait for num_rendered) down with it — so the violation is flagged instead: the
+                // point is culled like any other, counters[1] tells the host, and the call returns an error.
+                if (a.prefiltered) g.counters[1] = 1u;
                 break;
             }
             const float hx = pm[0] * px + pm[4] * py + pm[8] * pz + pm[12];
@@ -415,6 +418,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_bl
         g.counters[0] = chunk_base;   // num_rendered
         if (host_counter) {   // straight into host-mapped memory, value first, then the call's sequence number: the host polls it
             __hip_atomic_store(&host_counter[0], chunk_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_counter[2], g.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // prefilter flag
             __hip_atomic_store(&host_counter[1], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

@@ -70,6 +70,8 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
     const float T_final = inside ? a.final_T[pix_id] : 0.f;
     float T = T_final;
     const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
+    // list position of the splat at which this pixel's T crossed 0.5 in the forward (-1: never): it receives dL_dmedian_depth
+    const int median_at = (inside && BASE ? (int)a.median_pos[pix_id] : 0) - 1;
 
     // nothing behind the tile's farthest contributor can receive gradient: start there
     int wmax = last_contributor;
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
                     v[7] = w * dpx1;
                     v[8] = w * dpx2;
                     // depth (+ median-depth gradient at the T = 0.5 crossing, backward.cu:618-626)
-                    v[9] = w * dpd + ((active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f);
+                    v[9] = w * dpd + ((active && pos == median_at) ? dpm : 0.f);
                     dL_dalpha += (-T_final * inv_one_m_a) * bg_dot;
                     // rejected lanes contribute nothing (and exp2 of a positive power may be inf)
                     const float Gs = active ? G : 0.f;
@@ -274,12 +276,17 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
     if (use_mfma && (a.semantic ? a.K : 0) <= 27) {  // one matrix-core launch covers the base sums + K <= 27 channels
         // default: 16-lane groups on 4x4 sub-block masks (hsr_render_bwd_sub.hip, packed rows only), 0.37 ms at the headline
         // workload; HSR_BWD_IMPL=mfma: all 64 lanes on the quadrant list (hsr_render_bwd_mfma.hip, 0.42 ms; also serves the
-        // legacy accumulation mode); HSR_BWD_IMPL=mom: the opt-in moments variant
+        // legacy accumulation mode); HSR_BWD_IMPL=mom (ablate build only): the moments experiment
         static const char* impl = getenv("HSR_BWD_IMPL");
         static const bool use_quad = impl && !strcmp(impl, "mfma");
+#ifdef HSR_ABLATE
         static const bool use_mom = impl && !strcmp(impl, "mom");
-        if (use_mom && a.grow) hsr_launch_render_backward_mom(a, stream);
-        else if (!use_quad && a.grow) hsr_launch_render_backward_sub(a, stream);
+        if (use_mom && a.grow) {
+            hsr_launch_render_backward_mom(a, stream);
+            return HSR_OK;
+        }
+#endif
+        if (!use_quad && a.grow) hsr_launch_render_backward_sub(a, stream);
         else hsr_launch_render_backward_mfma(a, stream);
         return HSR_OK;
     }

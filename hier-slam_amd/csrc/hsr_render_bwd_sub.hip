@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     const float inm = inside ? 1.f : 0.f;
     const float T_final_ld = a.final_T[pix_ld];
     const int last_contributor_ld = (int)a.n_contrib[pix_ld];
+    const int median_at_ld = (int)a.median_pos[pix_ld];
     float dpx0 = a.dL_dpix[pix_ld], dpx1 = a.dL_dpix[N + pix_ld], dpx2 = a.dL_dpix[2 * N + pix_ld];
     float dpd = a.dL_dpix_depth[pix_ld], dpm = a.dL_dpix_median[pix_ld], dpo = a.dL_dpix_opacity[pix_ld];
     float semv[KC > 0 ? KC : 1];
@@ -117,6 +118,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     const float T_final = T_final_ld * inm;
     float T = T_final;
     const int last_contributor = inside ? last_contributor_ld : 0;
+    const int median_at = (inside ? median_at_ld : 0) - 1;   // list position of the forward's T = 0.5 crossing (-1: none): gets dL_dmedian_depth
 
     int wmax = last_contributor;
 #pragma unroll
@@ -334,7 +336,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 v[3] = hq * dxy;
                 v[4] = hq * dyy;
                 v[5] = gda;
-                v[6] = (active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f;
+                v[6] = (active && pos == median_at) ? dpm : 0.f;
                 if (active) {
                     Rb = Rn;
                     last_h = h;
@@ -408,12 +410,14 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
     const float inm = inside ? 1.f : 0.f;
     const float T_final_ld = a.final_T[pix_ld];
     const int last_contributor_ld = (int)a.n_contrib[pix_ld];
+    const int median_at_ld = (int)a.median_pos[pix_ld];
     float dpx0 = a.dL_dpix[pix_ld], dpx1 = a.dL_dpix[N + pix_ld], dpx2 = a.dL_dpix[2 * N + pix_ld];
     float dpd = a.dL_dpix_depth[pix_ld], dpm = a.dL_dpix_median[pix_ld], dpo = a.dL_dpix_opacity[pix_ld];
     dpx0 *= inm; dpx1 *= inm; dpx2 *= inm; dpd *= inm; dpm *= inm; dpo *= inm;
     const float T_final = T_final_ld * inm;
     float T = T_final;
     const int last_contributor = inside ? last_contributor_ld : 0;
+    const int median_at = (inside ? median_at_ld : 0) - 1;   // list position of the forward's T = 0.5 crossing (-1: none): gets dL_dmedian_depth
 
     int wmax = last_contributor;
 #pragma unroll
@@ -557,7 +561,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                 v[3] = hq * dxy;
                 v[4] = hq * dyy;
                 v[5] = gda;
-                v[6] = fmaf(w, dpd, (active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f);   // depth: direct sum + median term
+                v[6] = fmaf(w, dpd, (active && pos == median_at) ? dpm : 0.f);   // depth: direct sum + median term
                 if (active) {
                     Rb = Rn;
                     last_h = h;
@@ -612,6 +616,7 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : 3) render_bwd_subw_kernel(R
     const float inm = inside ? 1.f : 0.f;
     const float T_final_ld = a.final_T[pix_ld];
     const int last_contributor_ld = (int)a.n_contrib[pix_ld];
+    const int median_at_ld = (int)a.median_pos[pix_ld];
     float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f, dpd = 0.f, dpm = 0.f, dpo = 0.f;
     if (BASE) {
         dpx0 = a.dL_dpix[pix_ld] * inm; dpx1 = a.dL_dpix[N + pix_ld] * inm; dpx2 = a.dL_dpix[2 * N + pix_ld] * inm;
@@ -620,6 +625,7 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : 3) render_bwd_subw_kernel(R
     const float T_final = T_final_ld * inm;
     float T = T_final;
     const int last_contributor = inside ? last_contributor_ld : 0;
+    const int median_at = (inside ? median_at_ld : 0) - 1;   // list position of the forward's T = 0.5 crossing (-1: none): gets dL_dmedian_depth
 
     int wmax = last_contributor;
 #pragma unroll
@@ -827,7 +833,7 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : 3) render_bwd_subw_kernel(R
                 v[3] = hq * dxy;
                 v[4] = hq * dyy;
                 v[5] = gda;
-                v[6] = (active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f;
+                v[6] = (active && pos == median_at) ? dpm : 0.f;
                 if (active) {
                     Rb = Rn;
                     last_h = h;

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256, 2) render_bwd_wide_kernel(RenderBwdArgs a
     const float inm = inside ? 1.f : 0.f;
     const float T_final_ld = a.final_T[pix_ld];
     const int last_contributor_ld = (int)a.n_contrib[pix_ld];
+    const int median_at_ld = (int)a.median_pos[pix_ld];
     float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f, dpd = 0.f, dpm = 0.f, dpo = 0.f;
     if (BASE) {
         dpx0 = a.dL_dpix[pix_ld] * inm; dpx1 = a.dL_dpix[N + pix_ld] * inm; dpx2 = a.dL_dpix[2 * N + pix_ld] * inm;
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(256, 2) render_bwd_wide_kernel(RenderBwdArgs a
     const float T_final = T_final_ld * inm;
     float T = T_final;
     const int last_contributor = inside ? last_contributor_ld : 0;
+    const int median_at = (inside ? median_at_ld : 0) - 1;   // list position of the forward's T = 0.5 crossing (-1: none): gets dL_dmedian_depth
 
     int wmax = last_contributor;
 #pragma unroll
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(256, 2) render_bwd_wide_kernel(RenderBwdArgs a
                         v[3] = hq * dxy;
                         v[4] = hq * dyy;
                         v[5] = gda;
-                        v[6] = (active && test_T > 0.5f && T < 0.5f) ? dpm : 0.f;
+                        v[6] = (active && pos == median_at) ? dpm : 0.f;
                         if (active) {
                             Rb = Rn;
                             last_h = h;

@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0, Dd = 0, Mm = 0, median_D = 15.0f;
+    uint32_t median_at = 0;   // 1 + list position of the splat at which T crossed 0.5 (ImgState::median_pos)
     float S[KC > 0 ? KC : 1];
 #pragma unroll
     for (int c = 0; c < (KC > 0 ? KC : 1); c++) S[c] = 0.f;
@@ -223,7 +224,10 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
                             else if (BASE && c == KC) C2 = fmaf(fv[i], w, C2);
                             else if (BASE && c == KC + 1) {
                                 Dd = fmaf(fv[i], w, Dd);
-                                if (contrib && T > 0.5f && test_T < 0.5f) median_D = fv[i];
+                                if (contrib && T > 0.5f && test_T < 0.5f) {
+                                    median_D = fv[i];
+                                    median_at = (uint32_t)(start + j + 1);
+                                }
                             }
                         }
                     }
@@ -275,7 +279,10 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
                             else if (BASE && c == KC) C2 = fmaf(fv[i], w, C2);
                             else if (BASE && c == KC + 1) {
                                 Dd = fmaf(fv[i], w, Dd);
-                                if (contrib && T > 0.5f && test_T < 0.5f) median_D = fv[i];
+                                if (contrib && T > 0.5f && test_T < 0.5f) {
+                                    median_D = fv[i];
+                                    median_at = (uint32_t)(start + j + 1);
+                                }
                             }
                         }
                     }
@@ -293,6 +300,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : 1) render_fwd_ker
         if (BASE) {
             a.final_T[pix_id] = T;
             a.n_contrib[pix_id] = last_contributor;
+            a.median_pos[pix_id] = median_at;
             a.out_color[pix_id] = C0;
             a.out_color[N + pix_id] = C1;
             a.out_color[2 * N + pix_id] = C2;
@@ -317,13 +325,15 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     const dim3 grid(hsr_tile_grid(tiles)), block(256);
     // Default for K <= 28: the per-lane kernel on 4x4 sub-block lists (SUB).  Measured at the headline workload (500k
     // Gaussians, 1200x680, K = 26): 0.18 ms against 0.22 ms for the same kernel on quadrant lists (HSR_FWD_IMPL=valu, kept
-    // for A/B timing and tests) and 0.27 ms for the pair-pipelined matrix-core kernel (HSR_FWD_IMPL=mfma,
-    // hsr_render_fwd_pair.hip: the ~25 VALU instructions that evaluate alpha per list entry dominate, the matrix cores
+    // for A/B timing and tests) and 0.27 ms for the pair-pipelined matrix-core kernel (HSR_FWD_IMPL=mfma in the ablate build,
+    // experiments/hsr_render_fwd_pair.hip: the ~25 VALU instructions that evaluate alpha per list entry dominate, the matrix cores
     // only take the 15 packed FMAs behind them, and every list entry has to go through the pair).
     static const char* impl = getenv("HSR_FWD_IMPL");
-    static const bool use_pair = impl && !strcmp(impl, "mfma");
     static const bool force_valu = impl && !strcmp(impl, "valu");   // quadrant lists, per-lane accumulators for every K
+#ifdef HSR_ABLATE
+    static const bool use_pair = impl && !strcmp(impl, "mfma");
     if (use_pair && hsr_launch_render_forward_pair(a, stream)) return HSR_OK;
+#endif
     if (!a.semantic) {
         if (force_valu) render_fwd_kernel<0, true, true, false, false><<<grid, block, 0, stream>>>(a, 0);
         else render_fwd_kernel<0, true, true, false, true><<<grid, block, 0, stream>>>(a, 0);

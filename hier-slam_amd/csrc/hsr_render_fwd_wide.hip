@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(256, 2) render_fwd_wide_kernel(RenderFwdArgs a
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float median_D = 15.0f;
+    uint32_t median_at = 0;   // 1 + list position of the splat at which T crossed 0.5 (ImgState::median_pos)
     bool done = !inside;
     f32x16 D[2][NB];  // OUT[pixels 0-31 | 32-63][channel block]
 #pragma unroll
@@ -183,7 +184,10 @@ __global__ void __launch_bounds__(256, 2) render_fwd_wide_kernel(RenderFwdArgs a
                 const bool cross = contrib && T > 0.5f && test_T < 0.5f;
                 if (__ballot(cross) != 0ull) {
                     const float dep = s_feat[j * FS + K + 3];
-                    if (cross) median_D = dep;
+                    if (cross) {
+                        median_D = dep;
+                        median_at = (uint32_t)(start + j + 1);
+                    }
                 }
                 if (contrib) {
                     T = test_T;
@@ -212,6 +216,7 @@ __global__ void __launch_bounds__(256, 2) render_fwd_wide_kernel(RenderFwdArgs a
     if (inside) {
         a.final_T[pix_id] = T;
         a.n_contrib[pix_id] = last_contributor;
+        a.median_pos[pix_id] = median_at;
         a.out_median_depth[pix_id] = median_D;
         a.out_opacity[pix_id] = 1.0f - T;
     }
@@ -243,7 +248,7 @@ __global__ void __launch_bounds__(256, 2) render_fwd_wide_kernel(RenderFwdArgs a
 bool hsr_launch_render_forward_wide(const RenderFwdArgs& a_, hipStream_t stream)
 {
     RenderFwdArgs a = a_;
-    static const int dbg = getenv("HSR_FWD_DEBUG") ? atoi(getenv("HSR_FWD_DEBUG")) : 0;
+    static const int dbg = hsr_ablate_env("HSR_FWD_DEBUG") ? atoi(hsr_ablate_env("HSR_FWD_DEBUG")) : 0;   // 0 in the product build
     a.debug_flags = dbg;
     if (!a.semantic || a.K < 29 || a.K > 124) return false;  // K + 4 channels must need 2..4 blocks of 32
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);

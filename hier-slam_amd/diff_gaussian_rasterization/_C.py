@@ -34,7 +34,7 @@ class _StateLayout(C.Structure):
         "geom_depths", "geom_means2D", "geom_conic_opacity", "geom_cov3D", "geom_rgb", "geom_clamped",
         "geom_tiles_touched", "geom_point_offsets", "geom_radii",
         "bin_keys_unsorted", "bin_keys", "bin_vals_unsorted", "bin_vals",
-        "img_ranges", "img_final_T", "img_n_contrib")]
+        "img_ranges", "img_final_T", "img_n_contrib", "img_median_pos")]
 
 
 def _load():
@@ -154,7 +154,8 @@ def _rows_or_legacy():
 
 
 def set_backward_mode(mode):
-    """'packed' (default), 'rows' (experimental, no global atomics) or 'legacy' (reference-style arrays)."""
+    """'packed' (default: one gradient row per Gaussian) or 'legacy' (atomics into the reference's six arrays); 'rows' exists in
+    the ablate build of the library only and is refused by the product."""
     rc = _lib.hsr_set_backward_mode({"packed": 0, "rows": 1, "legacy": 2}[mode])
     if rc < 0:
         _fail(rc, "hsr_set_backward_mode")

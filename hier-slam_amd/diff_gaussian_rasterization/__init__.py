@@ -42,7 +42,8 @@ class GaussianRasterizationSettings(NamedTuple):
 
 def _snapshot(args):
     """CPU deep copy of the call arguments, taken before the call in debug mode (reference :17-19)."""
-    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+    # numpy scalars (a tanfov computed with numpy) become Python numbers, so the dump loads with torch.load(weights_only=True)
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else (a.item() if hasattr(a, "item") else a) for a in args)
 
 
 def _call(fn, args, debug, dump_name, when, **options):

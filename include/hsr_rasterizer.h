@@ -160,6 +160,8 @@ typedef struct hsr_state_layout {
         geom_tiles_touched, geom_point_offsets, geom_radii;
     size_t bin_keys_unsorted, bin_keys, bin_vals_unsorted, bin_vals;
     size_t img_ranges, img_final_T, img_n_contrib;
+    size_t img_median_pos;   /* u32[N]: 1 + list position of the splat at which the pixel's T crossed 0.5 (0: never) — no
+                              * counterpart in the reference, whose backward re-derives it from a reconstructed T */
 } hsr_state_layout;
 int hsr_get_state_layout(int P, int width, int height, int num_rendered, hsr_state_layout* out);
 

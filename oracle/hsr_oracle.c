@@ -23,6 +23,15 @@
  * arbitrary order (backward.cu:616-663, :828-896).  Here each per-pair term is computed in fp32
  * exactly as the reference does and the per-Gaussian sum is kept in double, rounded to fp32 once:
  * order-independent, and within the reference's own fp32 noise of any of its summation orders.
+ *
+ * Median-depth gradient: the reference's backward finds the splat at which T crossed 0.5 again, from the
+ * T it reconstructs by dividing (backward.cu:623-626, :854-857).  That reconstruction is exact only up to
+ * rounding, so on a pixel whose T passes within an ulp of 0.5 the backward can pick the neighbouring
+ * splat, none, or two — an artefact of the arithmetic that differs between any two implementations
+ * (CUDA's expf / division included).  hsro_set_median_rule(0) (default) keeps the reference's rule;
+ * rule 1 uses the list position the FORWARD recorded for the crossing (field "median_pos"), which is what
+ * the HIP product does.  Every backward call counts the pixels on which the two rules disagree
+ * (hsro_last_median_rule_disagreements()), so a comparison can say how many there were.
  */
 #include <math.h>
 #include <stdint.h>
@@ -249,7 +258,13 @@ typedef struct HsroState {
     uint32_t* ranges;       /* [T,2]                                      (ImageState.ranges)           */
     float* final_T;         /* [N]                                        (ImageState.accum_alpha)      */
     uint32_t* n_contrib;    /* [N]                                        (ImageState.n_contrib)        */
+    uint32_t* median_pos;   /* [N] 1 + list position of the splat at which T crossed 0.5 (0: never); not in the reference */
 } HsroState;
+
+static int g_median_rule = 0;
+static long g_median_disagree = 0;
+void hsro_set_median_rule(int rule) { g_median_rule = rule ? 1 : 0; }
+long hsro_last_median_rule_disagreements(void) { return g_median_disagree; }
 
 void hsro_free(HsroState* s)
 {
@@ -257,6 +272,7 @@ void hsro_free(HsroState* s)
     free(s->depths); free(s->means2D); free(s->conic_opacity); free(s->cov3D); free(s->rgb); free(s->clamped);
     free(s->radii); free(s->tiles_touched); free(s->point_offsets); free(s->keys_unsorted); free(s->keys);
     free(s->vals_unsorted); free(s->vals); free(s->ranges); free(s->final_T); free(s->n_contrib);
+    free(s->median_pos);
     free(s);
 }
 
@@ -269,7 +285,7 @@ const void* hsro_field(const HsroState* s, int id)
     case 4: return s->rgb; case 5: return s->clamped; case 6: return s->radii; case 7: return s->tiles_touched;
     case 8: return s->point_offsets; case 9: return s->keys_unsorted; case 10: return s->keys;
     case 11: return s->vals_unsorted; case 12: return s->vals; case 13: return s->ranges; case 14: return s->final_T;
-    case 15: return s->n_contrib; default: return 0;
+    case 15: return s->n_contrib; case 16: return s->median_pos; default: return 0;
     }
 }
 
@@ -325,6 +341,7 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
     s->cov3D = (float*)calloc(Pa * 6, 4); s->rgb = (float*)calloc(Pa * 3, 4); s->clamped = (uint8_t*)calloc(Pa * 3, 1);
     s->radii = (int*)calloc(Pa, 4); s->tiles_touched = (uint32_t*)calloc(Pa, 4); s->point_offsets = (uint32_t*)calloc(Pa, 4);
     s->ranges = (uint32_t*)calloc(Tn * 2, 4); s->final_T = (float*)calloc(N, 4); s->n_contrib = (uint32_t*)calloc(N, 4);
+    s->median_pos = (uint32_t*)calloc(N, 4);
     s->has_sh = colors_precomp == 0; s->own_cov3d = cov3D_precomp == 0;
 
     /* rasterizer_impl.cu:226-227 */
@@ -432,6 +449,7 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
                 float pfx = (float)px, pfy = (float)py;
                 float T = 1.0f; uint32_t contributor = 0, last_contributor = 0;
                 float C[NUM_CHANNELS] = {0, 0, 0}; float Dd = 0; float median_D = 15.0f; float Mm = 0;
+                uint32_t median_at = 0;
                 for (int ch = 0; ch < K; ch++) Sacc[ch] = 0;
                 for (uint32_t i = r0; i < r1; i++) {
                     contributor++;
@@ -448,11 +466,11 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
                     Dd += s->depths[id] * alpha * T;
                     if (s->semantic) { for (int ch = 0; ch < K; ch++) Sacc[ch] += semantics[(size_t)id * K + ch] * alpha * T; }
                     else Mm += alpha * T;
-                    if (T > 0.5f && test_T < 0.5) median_D = s->depths[id]; /* forward.cu:371-376, :511-515 */
+                    if (T > 0.5f && test_T < 0.5) { median_D = s->depths[id]; median_at = contributor; } /* forward.cu:371-376, :511-515 */
                     T = test_T;
                     last_contributor = contributor;
                 }
-                s->final_T[pix_id] = T; s->n_contrib[pix_id] = last_contributor;
+                s->final_T[pix_id] = T; s->n_contrib[pix_id] = last_contributor; s->median_pos[pix_id] = median_at;
                 for (int ch = 0; ch < NUM_CHANNELS; ch++) out_color[(size_t)ch * N + pix_id] = C[ch];
                 out_depth[pix_id] = Dd; out_median_depth[pix_id] = median_D; out_opacity[pix_id] = 1 - T;
                 if (s->semantic) { for (int ch = 0; ch < K; ch++) out_semantic[(size_t)ch * N + pix_id] = Sacc[ch]; }
@@ -548,9 +566,11 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
     double* acc = (double*)calloc(Pa * (size_t)NA, sizeof(double));
     if (!acc) return -2;
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H); /* backward.cu:550-551, :759-760 */
+    const int median_rule = g_median_rule;
+    long median_disagree = 0;
 
     /* ---- renderCUDA (backward.cu:472-666) / renderCUDA_SEM (backward.cu:669-899) ---- */
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : median_disagree)
     for (long tile = 0; tile < (long)Tn; tile++) {
         const uint32_t ty = (uint32_t)(tile / gx), tx = (uint32_t)(tile % gx);
         const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
@@ -570,6 +590,8 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
                 const float dpd = dL_dpix_depth[pix_id], dpm = dL_dpix_median[pix_id], dpo = dL_dpix_opacity[pix_id];
                 for (int c = 0; c < K; c++) dsem[c] = dL_dpix_sem[(size_t)c * N + pix_id];
                 float accum_depth_rec = 0, accum_op_rec = 0, last_alpha = 0, last_depth = 0, last_op = 0;
+                const uint32_t median_at = s->median_pos[pix_id];
+                int pixel_disagrees = 0;
                 for (uint32_t ii = r1; ii > r0; ii--) { /* back to front, backward.cu:562, :771 */
                     contributor--;
                     if ((int64_t)contributor >= (int64_t)last_contributor) continue;
@@ -610,9 +632,14 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
 #pragma omp atomic
                         a[9] += (double)v;
                     }
-                    if (test_T > 0.5f && T < 0.5) { /* backward.cu:623-626, :854-857 */
+                    {
+                        const int by_reference_rule = (test_T > 0.5f && T < 0.5); /* backward.cu:623-626, :854-857 */
+                        const int by_forward_record = (contributor + 1 == median_at);
+                        if (by_reference_rule != by_forward_record) pixel_disagrees = 1;
+                        if (median_rule ? by_forward_record : by_reference_rule) {
 #pragma omp atomic
-                        a[9] += (double)dpm;
+                            a[9] += (double)dpm;
+                        }
                     }
                     accum_op_rec = last_alpha * last_op + (1.f - last_alpha) * accum_op_rec;
                     last_op = 1.f;
@@ -648,9 +675,11 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
 #pragma omp atomic
                     a[5] += (double)v5;
                 }
+                median_disagree += pixel_disagrees;
             }
         free(dsem);
     }
+    g_median_disagree = median_disagree;
     for (int i = 0; i < P; i++) {
         const double* a = acc + (size_t)i * NA;
         dL_dmean2D[3 * i] = (float)a[0]; dL_dmean2D[3 * i + 1] = (float)a[1]; dL_dmean2D[3 * i + 2] = 0.f;

@@ -47,6 +47,7 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     tr = terminalreporter
     tr.write_sep("-", "observed errors vs the oracle (worst over %d comparisons; bound %.0e, element-wise floor %.2g of max)" % (
         len(harness.OBSERVED), harness.RTOL, harness.FLOOR_FRAC))
+    tr.write_line("(scales / rotations / cov3D are held to floor %.2g: tests/harness.py)" % harness.FLOOR_FRAC_COV)
     for name in sorted(worst):
         w = worst[name]
         tr.write_line("%-28s n=%-4d err/max %.2e   element-wise at floor 1/0.1/0.01/0.001: %s" % (

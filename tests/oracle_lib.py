@@ -13,7 +13,8 @@ _SO = os.path.join(_ROOT, "oracle", "libhsr_oracle.so")
 _lib = None
 
 FIELDS = dict(depths=0, means2D=1, conic_opacity=2, cov3D=3, rgb=4, clamped=5, radii=6, tiles_touched=7,
-              point_offsets=8, keys_unsorted=9, keys=10, vals_unsorted=11, vals=12, ranges=13, final_T=14, n_contrib=15)
+              point_offsets=8, keys_unsorted=9, keys=10, vals_unsorted=11, vals=12, ranges=13, final_T=14, n_contrib=15,
+              median_pos=16)
 
 
 def build(force=False):
@@ -36,6 +37,8 @@ def lib():
         _lib.hsro_free.argtypes = [C.c_void_p]
         _lib.hsro_get_higher_msb.restype = C.c_uint32
         _lib.hsro_get_higher_msb.argtypes = [C.c_uint32]
+        _lib.hsro_set_median_rule.argtypes = [C.c_int]
+        _lib.hsro_last_median_rule_disagreements.restype = C.c_long
     return _lib
 
 
@@ -71,7 +74,7 @@ class OracleState:
                     radii=(np.int32, (P,)), tiles_touched=(np.uint32, (P,)), point_offsets=(np.uint32, (P,)),
                     keys_unsorted=(np.uint64, (R,)), keys=(np.uint64, (R,)), vals_unsorted=(np.uint32, (R,)),
                     vals=(np.uint32, (R,)), ranges=(np.uint32, (T, 2)), final_T=(np.float32, (N,)),
-                    n_contrib=(np.uint32, (N,)))[name]
+                    n_contrib=(np.uint32, (N,)), median_pos=(np.uint32, (N,)))[name]
         n = int(np.prod(spec[1]))
         if n == 0:
             return np.zeros(spec[1], dtype=spec[0])
@@ -144,9 +147,14 @@ def forward(cam, means3D, opacities, colors_precomp=None, shs=None, semantics_pr
 
 
 def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_precomp=None, scales=None,
-             rotations=None, cov3D_precomp=None, threads=0):
-    """Oracle backward.  grads: dict(color[3,H,W], semantic[K,H,W]|None, depth, median, opacity)."""
+             rotations=None, cov3D_precomp=None, threads=0, median_rule="reference"):
+    """Oracle backward.  grads: dict(color[3,H,W], semantic[K,H,W]|None, depth, median, opacity).
+    median_rule: "reference" = the splat the backward re-finds from its reconstructed T (backward.cu:623-626, :854-857);
+    "forward" = the splat whose list position the forward recorded (what the HIP product does; identical except where the
+    reconstructed T passes within rounding of 0.5).  The result carries `median_rule_disagreements`: the number of pixels on
+    which the two rules pick differently."""
     L = lib()
+    L.hsro_set_median_rule(C.c_int({"reference": 0, "forward": 1}[median_rule]))
     if threads:
         L.hsro_set_threads(C.c_int(threads))
     g = (lambda k: cam[k]) if isinstance(cam, dict) else (lambda k: getattr(cam, k))
@@ -178,6 +186,8 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
                          C.c_int(0))
     if rc != 0:
         raise RuntimeError("hsro_backward rc=%d" % rc)
+    o["median_rule_disagreements"] = int(L.hsro_last_median_rule_disagreements())
+    L.hsro_set_median_rule(C.c_int(0))
     return o
 
 

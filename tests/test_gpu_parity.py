@@ -61,6 +61,8 @@ def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
     npix = out_o["color"].shape[1] * out_o["color"].shape[2]
     nmis = int((st_g["n_contrib"] != st_o.field("n_contrib")).sum())
     assert nmis <= max(2, npix // 2000), "n_contrib mismatches: %d" % nmis
+    mmis = int((st_g["median_pos"] != st_o.field("median_pos")).sum())   # the recorded T = 0.5 crossing: same kind of tie
+    assert mmis <= max(2, npix // 2000), "median_pos mismatches: %d" % mmis
     # ---- images ----
     names = ["color", "depth", "opacity"] + (["semantic"] if semantic else ["mask"])
     for n in names:
@@ -255,3 +257,64 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _render_sem(cam, sc, dev, **flags):
+    from diff_gaussian_rasterization import GaussianRasterizer_semantic
+    from harness import _cam_to
+    c = dict(cam)
+    c.update(flags)
+    leaf = {n: sc[n].to(dev).clone().requires_grad_(True) for n in ("means3D", "opacities", "colors_precomp", "scales", "rotations",
+                                                                    "semantics_precomp")}
+    m2 = torch.zeros(sc["means3D"].shape[0], 3, device=dev, requires_grad=True)
+    return leaf, GaussianRasterizer_semantic(_cam_to(c, dev))(means2D=m2, **leaf)
+
+
+def test_prefiltered_violation_is_an_error_not_a_device_trap():
+    """prefiltered=True promises that every point passes the frustum test; the reference __trap()s the device when one does
+    not (auxiliary.h:156-160).  Here the call raises with the reference's message and the context keeps working."""
+    dev = torch.device("cuda:0")
+    cam, sc, up = scenes.build(96, 64, 1500, 16, seed=2, behind_frac=0.3)     # 30 % of the points behind / too near the camera
+    with pytest.raises(RuntimeError, match="filtered although prefiltered is set"):
+        _render_sem(cam, sc, dev, prefiltered=True)
+    torch.cuda.synchronize()
+    # the same scene without the promise renders, and so does a promise that holds — through the whole comparison
+    _compare(cam, sc, up, True, "sr", None)
+    cam2, sc2, up2 = scenes.build(96, 64, 1500, 16, seed=2, behind_frac=0.0)
+    cam2["prefiltered"] = True
+    _compare(cam2, sc2, up2, True, "sr", None)
+
+
+def test_debug_mode_checks_every_launch_and_dumps_snapshots(tmp_path, monkeypatch):
+    """raster_settings.debug=True (auxiliary.h:166-173 sync-and-throw after every launch; __init__.py:82-90 / :294-301
+    input snapshots on failure): parity with every launch checked, snapshot_fw.dump / snapshot_bw.dump written on an
+    injected failure and loadable without unpickling code."""
+    from diff_gaussian_rasterization import _C
+    monkeypatch.chdir(tmp_path)
+    dev = torch.device("cuda:0")
+    cam, sc, up = scenes.build(96, 64, 1200, 16, seed=4)
+    cam["debug"] = True
+    _compare(cam, sc, up, True, "sr", None)               # per-launch checks on, no speculation: same results
+    assert not os.path.exists("snapshot_fw.dump") and not os.path.exists("snapshot_bw.dump")
+    bad = dict(sc)
+    bad["semantics_precomp"] = sc["semantics_precomp"][:-7]          # wrong row count: the forward refuses it
+    with pytest.raises(RuntimeError, match="semantics_precomp"):
+        _render_sem(cam, bad, dev)
+    snap = torch.load("snapshot_fw.dump", weights_only=True)
+    assert isinstance(snap, tuple) and snap[1].shape == (1200, 3) and snap[3].shape == (1193, 16) and not snap[1].is_cuda
+    # backward: inject a failure below the autograd node
+    leaf, outs = _render_sem(cam, sc, dev)
+    def boom(*a, **k):
+        raise RuntimeError("injected backward failure")
+    monkeypatch.setattr(_C, "rasterize_gaussians_backward_semantic", boom)
+    with pytest.raises(RuntimeError, match="injected backward failure"):
+        outs[0].sum().backward()
+    snap = torch.load("snapshot_bw.dump", weights_only=True)
+    assert isinstance(snap, tuple) and snap[1].shape == (1200, 3) and int(snap[-4]) == outs[0].grad_fn.num_rendered
+    # without debug nothing is dumped
+    os.remove("snapshot_fw.dump"); os.remove("snapshot_bw.dump")
+    cam["debug"] = False
+    leaf, outs = _render_sem(cam, sc, dev)
+    with pytest.raises(RuntimeError):
+        outs[0].sum().backward()
+    assert not os.path.exists("snapshot_bw.dump")
