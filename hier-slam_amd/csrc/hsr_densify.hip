@@ -148,7 +148,147 @@ __global__ __launch_bounds__(DB) void emit_points_kernel(const float* __restrict
 
 size_t dalign(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// ---- prune + concat of the map (utils/slam_external.py:121-188) as ONE order-preserving row compaction --------------------
+// keep mask of prune_gaussians (:175-180): to_remove = sigmoid(logit_opacity) < threshold  |  max_c exp(log_scale_c) > big
+__global__ __launch_bounds__(DB) void prune_mask_kernel(int P, int S, const float* __restrict__ logit, const float* __restrict__ lscale,
+                                                        float thr, float big, uint8_t* __restrict__ keep, unsigned* __restrict__ counts)
+{
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * DB + threadIdx.x;
+    bool k = false;
+    if (i < P) {
+        const float sg = 1.0f / (1.0f + expf(-logit[i]));          // torch.sigmoid
+        bool rem = sg < thr;
+        if (big > 0.f && lscale) {
+            float m = expf(lscale[(size_t)i * S]);
+            for (int c = 1; c < S; c++) m = fmaxf(m, expf(lscale[(size_t)i * S + c]));
+            rem = rem || (m > big);
+        }
+        k = !rem;
+        keep[i] = k ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(k);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(DB) void count_keep_kernel(int P, const uint8_t* __restrict__ keep, unsigned* __restrict__ counts)
+{
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * DB + threadIdx.x;
+    const unsigned long long b = __ballot(i < P && keep[i] != 0);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void add_int_kernel(int* v, int base, int add, int overwrite) { *v = (overwrite ? base : *v) + add; }
+struct RowTables {
+    int n;
+    hsr_row_table t[HSR_MAX_ROW_TABLES];
+};
+// rows [0, P): kept rows move to their rank (block offset + ballot rank: source order is preserved, which is what
+// `tensor[to_keep]` yields); rows [P, P + n_append): the appended rows (or zeros: fresh Adam moments) land behind them
+__global__ __launch_bounds__(DB) void compact_append_kernel(int P, int n_append, const uint8_t* __restrict__ keep,
+                                                            const unsigned* __restrict__ offsets, const int* __restrict__ kept_total,
+                                                            RowTables tb)
+{
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * DB + threadIdx.x;
+    const int nblk_keep = (P + DB - 1) / DB;
+    if ((int)blockIdx.x < nblk_keep) {
+        const bool k = i < P && (!keep || keep[i] != 0);
+        const unsigned long long b = __ballot(k);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) s_w[w] = (unsigned)__popcll(b);
+        __syncthreads();
+        if (!k) return;
+        size_t pos = (keep ? offsets[blockIdx.x] : (unsigned)(blockIdx.x * DB)) + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+        for (int q = 0; q < w; q++) pos += s_w[q];
+        for (int t = 0; t < tb.n; t++) {
+            const int C = tb.t[t].cols;
+            const float* src = tb.t[t].src + (size_t)i * C;
+            float* dst = tb.t[t].dst + pos * C;
+            for (int c = 0; c < C; c++) dst[c] = src[c];
+        }
+        return;
+    }
+    const int a = i - nblk_keep * DB;
+    if (a >= n_append) return;
+    const size_t pos = (size_t)(keep ? *kept_total : P) + a;
+    for (int t = 0; t < tb.n; t++) {
+        const int C = tb.t[t].cols;
+        float* dst = tb.t[t].dst + pos * C;
+        const float* app = tb.t[t].append;
+        for (int c = 0; c < C; c++) dst[c] = app ? app[(size_t)a * C + c] : 0.f;
+    }
+}
+
 }  // namespace
+
+extern "C" size_t hsr_compact_scratch_bytes(int P)
+{
+    const size_t nblk = ((size_t)(P > 0 ? P : 1) + DB - 1) / DB;
+    return dalign(nblk * sizeof(unsigned)) + 512;
+}
+
+extern "C" int hsr_prune_mask(int P, int S, const float* logit_opacities, const float* log_scales, float removal_opacity_threshold,
+                              float big_world_threshold, uint8_t* out_keep, int* out_kept, char* scratch, size_t scratch_bytes,
+                              void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || !out_kept || (P > 0 && (!logit_opacities || !out_keep)) || (big_world_threshold > 0.f && (S < 1 || !log_scales))) {
+        hsr_set_error("prune_mask: invalid arguments (P=%d S=%d)", P, S);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!scratch || scratch_bytes < hsr_compact_scratch_bytes(P)) {
+        hsr_set_error("prune_mask: scratch too small: %zu bytes needed", hsr_compact_scratch_bytes(P));
+        return HSR_ERR_BUFFER_TOO_SMALL;
+    }
+    unsigned* counts = reinterpret_cast<unsigned*>(scratch);
+    const int nblk = (P + DB - 1) / DB;
+    if (P > 0)
+        prune_mask_kernel<<<nblk, DB, 0, stream>>>(P, S, logit_opacities, log_scales, removal_opacity_threshold, big_world_threshold,
+                                                   out_keep, counts);
+    scan_counts_kernel<<<1, 1024, 0, stream>>>(nblk, counts, out_kept);   // counts -> exclusive offsets (what compact needs), total
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+extern "C" int hsr_compact_append_rows(int P, const uint8_t* keep, int keep_is_scanned, int n_tables, const hsr_row_table* tables,
+                                       int n_append, int* out_rows, char* scratch, size_t scratch_bytes, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || n_append < 0 || n_tables < 0 || n_tables > HSR_MAX_ROW_TABLES || (n_tables > 0 && !tables) || !out_rows) {
+        hsr_set_error("compact_append_rows: invalid arguments (P=%d n_append=%d n_tables=%d, at most %d tables)", P, n_append, n_tables,
+                      HSR_MAX_ROW_TABLES);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    RowTables tb;
+    tb.n = n_tables;
+    for (int t = 0; t < n_tables; t++) {
+        tb.t[t] = tables[t];
+        if (tb.t[t].cols < 1 || !tb.t[t].dst || (P > 0 && !tb.t[t].src)) {
+            hsr_set_error("compact_append_rows: table %d needs cols >= 1, dst and (for P > 0) src", t);
+            return HSR_ERR_INVALID_ARGUMENT;
+        }
+    }
+    if (!scratch || scratch_bytes < hsr_compact_scratch_bytes(P)) {
+        hsr_set_error("compact_append_rows: scratch too small: %zu bytes needed", hsr_compact_scratch_bytes(P));
+        return HSR_ERR_BUFFER_TOO_SMALL;
+    }
+    unsigned* counts = reinterpret_cast<unsigned*>(scratch);
+    const int nblk = (P + DB - 1) / DB;
+    if (keep && !keep_is_scanned) {   // a caller-made mask: count and scan it here
+        if (P > 0) count_keep_kernel<<<nblk, DB, 0, stream>>>(P, keep, counts);
+        scan_counts_kernel<<<1, 1024, 0, stream>>>(nblk, counts, out_rows);
+    }
+    const int ablk = (n_append + DB - 1) / DB;
+    if (nblk + ablk > 0 && n_tables > 0)
+        compact_append_kernel<<<nblk + ablk, DB, 0, stream>>>(P, n_append, keep, counts, out_rows, tb);
+    add_int_kernel<<<1, 1, 0, stream>>>(out_rows, keep ? 0 : P, n_append, keep ? 0 : 1);   // out_rows = kept + appended
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
 
 extern "C" size_t hsr_densify_scratch_bytes(int H, int W)
 {

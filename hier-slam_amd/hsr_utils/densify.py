@@ -3,8 +3,12 @@
     non_presence_points(...)                 mask (scripts/hierslam.py:1271-1278, :1289-1290) + get_pointcloud(..., mask=...,
                                              compute_mean_sq_dist=True) (:144-194) in one device pipeline (include/hsr_densify.h)
     initialize_new_params_semantic(...)      scripts/hierslam.py:1137-1167
-    add_new_gaussians_semantic(...)          scripts/hierslam.py:1264-1305 (renders depth + silhouette with the fused input
-                                             preparation and the rasterizer of this repo, then the two functions above)
+    initialize_new_params(...)               scripts/hierslam.py:1110-1135
+    add_new_gaussians_semantic_newrender(...) scripts/hierslam.py:1307-1352 — the one the mapping loop calls for semantic maps (:1949)
+    add_new_gaussians_newtest(...)           scripts/hierslam.py:1214-1262 — the one it calls for plain maps (:1945)
+    add_new_gaussians_semantic(...)          scripts/hierslam.py:1264-1305 (depth + silhouette render; dead in the reference's loop)
+each = fused input preparation + ONE no-grad render with this repo's rasterizer + non_presence_points + the concatenation.
+Prune / optimizer-preserving concat: hsr_utils/slam_external.py (one fused device compaction).
 
 The Parameter / bookkeeping concatenation is torch, as in the reference (it is bookkeeping on torch objects)."""
 import ctypes as C
@@ -74,8 +78,61 @@ def initialize_new_params_semantic(new_pt_cld, mean3_sq_dist, num_labels, log_sc
     return {k: torch.nn.Parameter(v.float().contiguous().requires_grad_(True)) for k, v in params.items()}
 
 
+def initialize_new_params(new_pt_cld, mean3_sq_dist, gaussian_distribution, log_scales=None):
+    """scripts/hierslam.py:1110-1135 (the map without semantic logits)."""
+    num_pts = new_pt_cld.shape[0]
+    dev = new_pt_cld.device
+    unnorm_rots = torch.zeros((num_pts, 4), dtype=torch.float32, device=dev)
+    unnorm_rots[:, 0] = 1.0
+    ls = log_scales if log_scales is not None else torch.log(torch.sqrt(mean3_sq_dist))[..., None]
+    if gaussian_distribution == "isotropic":
+        ls = torch.tile(ls.reshape(-1, 1), (1, 1))
+    elif gaussian_distribution == "anisotropic":
+        ls = torch.tile(ls.reshape(-1, 1), (1, 3))
+    else:
+        raise ValueError(f"Unknown gaussian_distribution {gaussian_distribution}")
+    params = {
+        'means3D': new_pt_cld[:, :3],
+        'rgb_colors': new_pt_cld[:, 3:6],
+        'unnorm_rotations': unnorm_rots,
+        'logit_opacities': torch.zeros((num_pts, 1), dtype=torch.float32, device=dev),
+        'log_scales': ls,
+    }
+    return {k: torch.nn.Parameter(v.float().contiguous().requires_grad_(True)) for k, v in params.items()}
+
+
+def _frame_w2c(params, time_idx):
+    """the frame's world-to-camera from the pose parameters (scripts/hierslam.py:1283-1287; build_rotation:
+    utils/slam_external.py:25-42)"""
+    cam_rot = torch.nn.functional.normalize(params['cam_unnorm_rots'][..., time_idx].detach())
+    curr_w2c = torch.eye(4, device=cam_rot.device)
+    r, x, y, z = (cam_rot / cam_rot.norm(dim=1, keepdim=True))[0]
+    curr_w2c[:3, :3] = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)]),
+                                    torch.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)]),
+                                    torch.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)])])
+    curr_w2c[:3, 3] = params['cam_trans'][0, :, time_idx].detach()
+    return curr_w2c
+
+
+def _grow_map(params, variables, new_params, time_idx, n_new):
+    """scripts/hierslam.py:1253-1260 / :1297-1304 / :1343-1350: concatenate, reset the densification statistics, stamp the
+    new points with the frame index.  (With an optimizer attached the reference rebuilds it afterwards, :1655-1666; the
+    optimizer-preserving form is hsr_utils.slam_external.cat_params_to_optimizer.)"""
+    for k, v in new_params.items():
+        params[k] = torch.nn.Parameter(torch.cat((params[k], v), dim=0).requires_grad_(True))
+    num_pts = params['means3D'].shape[0]
+    dev = params['means3D'].device
+    variables['means2D_gradient_accum'] = torch.zeros(num_pts, device=dev).float()
+    variables['denom'] = torch.zeros(num_pts, device=dev).float()
+    variables['max_2D_radius'] = torch.zeros(num_pts, device=dev).float()
+    new_timestep = time_idx * torch.ones(n_new, device=dev).float()
+    variables['timestep'] = torch.cat((variables['timestep'], new_timestep), dim=0)
+    return params, variables
+
+
 def add_new_gaussians_semantic(params, variables, curr_data, sil_thres, time_idx, mean_sq_dist_method, num_semantic):
-    """scripts/hierslam.py:1264-1305.  curr_data: 'cam', 'w2c', 'depth' [1,H,W], 'im' [3,H,W], 'intrinsics' [3,3]."""
+    """scripts/hierslam.py:1264-1305 (silhouette from the depth+silhouette render; NOT what the reference's loop calls — it
+    calls the two functions below).  curr_data: 'cam', 'w2c', 'depth' [1,H,W], 'im' [3,H,W], 'intrinsics' [3,3]."""
     from diff_gaussian_rasterization import GaussianRasterizer as Renderer
     from . import slam_helpers as SH
     if mean_sq_dist_method != "projective":
@@ -84,24 +141,57 @@ def add_new_gaussians_semantic(params, variables, curr_data, sil_thres, time_idx
     rv = SH.transformed_params2depthplussilhouette(params, curr_data['w2c'], tg)
     with torch.no_grad():
         depth_sil = Renderer(raster_settings=curr_data['cam'])(**rv)[0]
-        cam_rot = torch.nn.functional.normalize(params['cam_unnorm_rots'][..., time_idx].detach())
-        curr_w2c = torch.eye(4, device=cam_rot.device)
-        r, x, y, z = (cam_rot / cam_rot.norm(dim=1, keepdim=True))[0]
-        curr_w2c[:3, :3] = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)]),
-                                        torch.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)]),
-                                        torch.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)])])
-        curr_w2c[:3, 3] = params['cam_trans'][0, :, time_idx].detach()
         new_pt_cld, mean3_sq_dist, mask, log_scales = non_presence_points(depth_sil[1], depth_sil[0], curr_data['depth'][0], curr_data['im'],
-                                                                          curr_data['intrinsics'], curr_w2c, sil_thres)
+                                                                          curr_data['intrinsics'], _frame_w2c(params, time_idx), sil_thres)
     if new_pt_cld.shape[0] > 0:
         new_params = initialize_new_params_semantic(new_pt_cld, mean3_sq_dist, num_semantic, log_scales)
-        for k, v in new_params.items():
-            params[k] = torch.nn.Parameter(torch.cat((params[k], v), dim=0).requires_grad_(True))
-        num_pts = params['means3D'].shape[0]
-        dev = params['means3D'].device
-        variables['means2D_gradient_accum'] = torch.zeros(num_pts, device=dev).float()
-        variables['denom'] = torch.zeros(num_pts, device=dev).float()
-        variables['max_2D_radius'] = torch.zeros(num_pts, device=dev).float()
-        new_timestep = time_idx * torch.ones(new_pt_cld.shape[0], device=dev).float()
-        variables['timestep'] = torch.cat((variables['timestep'], new_timestep), dim=0)
+        params, variables = _grow_map(params, variables, new_params, time_idx, new_pt_cld.shape[0])
+    return params, variables
+
+
+def add_new_gaussians_semantic_newrender(params, variables, curr_data, sil_thres, time_idx, mean_sq_dist_method, num_semantic,
+                                         flag_use_render=1):
+    """scripts/hierslam.py:1307-1352 — what the mapping loop calls for semantic maps (:1949): ONE no-grad render with the
+    SEMANTIC rasterizer; silhouette = its final opacity (:1317), depth = its alpha-blended depth (:1322)."""
+    from diff_gaussian_rasterization import GaussianRasterizer_semantic as Renderer_semantic
+    from . import slam_helpers as SH
+    if mean_sq_dist_method != "projective":
+        raise ValueError(f"Unknown mean_sq_dist_method {mean_sq_dist_method}")
+    if flag_use_render != 1:
+        raise ValueError("flag_use_render must be 1 (the reference defines no other branch, scripts/hierslam.py:1313-1315)")
+    tg = SH.transform_to_frame(params, time_idx, gaussians_grad=False, camera_grad=False)
+    rv = SH.transformed_params2rendervar_semantic(params, tg)
+    with torch.no_grad():
+        im, radius, im_semantic, rendered_depth, rendered_median_depth, rendered_final_opcity = \
+            Renderer_semantic(raster_settings=curr_data['cam'])(**rv)
+        new_pt_cld, mean3_sq_dist, mask, log_scales = non_presence_points(
+            rendered_final_opcity.squeeze(0), rendered_depth.squeeze(0), curr_data['depth'][0], curr_data['im'],
+            curr_data['intrinsics'], _frame_w2c(params, time_idx), sil_thres)
+    if new_pt_cld.shape[0] > 0:
+        new_params = initialize_new_params_semantic(new_pt_cld, mean3_sq_dist, num_semantic, log_scales)
+        params, variables = _grow_map(params, variables, new_params, time_idx, new_pt_cld.shape[0])
+    return params, variables
+
+
+def add_new_gaussians_newtest(params, variables, curr_data, sil_thres, time_idx, mean_sq_dist_method, gaussian_distribution,
+                              flag_use_render=1):
+    """scripts/hierslam.py:1214-1262 — what the mapping loop calls for maps without semantics (:1945): one no-grad render with
+    the plain rasterizer (6 outputs); silhouette = final opacity (:1225), depth = alpha-blended depth (:1230)."""
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from . import slam_helpers as SH
+    if mean_sq_dist_method != "projective":
+        raise ValueError(f"Unknown mean_sq_dist_method {mean_sq_dist_method}")
+    if flag_use_render != 1:
+        raise ValueError("flag_use_render=2 unpacks 4 outputs from a 6-output renderer in the reference (:1221-1222) and cannot run")
+    tg = SH.transform_to_frame(params, time_idx, gaussians_grad=False, camera_grad=False)
+    rv = SH.transformed_params2rendervar(params, tg)
+    with torch.no_grad():
+        im, radius, rendered_depth, rendered_median_depth, rendered_final_opcity, rendered_mask = \
+            Renderer(raster_settings=curr_data['cam'])(**rv)
+        new_pt_cld, mean3_sq_dist, mask, log_scales = non_presence_points(
+            rendered_final_opcity[0], rendered_depth[0], curr_data['depth'][0], curr_data['im'], curr_data['intrinsics'],
+            _frame_w2c(params, time_idx), sil_thres)
+    if new_pt_cld.shape[0] > 0:
+        new_params = initialize_new_params(new_pt_cld, mean3_sq_dist, gaussian_distribution, log_scales)
+        params, variables = _grow_map(params, variables, new_params, time_idx, new_pt_cld.shape[0])
     return params, variables

@@ -39,6 +39,37 @@ int hsr_densify_frame(int H, int W, const float* silhouette, const float* render
                       int* out_count, float* out_means3D, float* out_rgb, float* out_log_scales, float* out_mean_sq_dist,
                       uint8_t* out_mask, float* out_median, char* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- prune + concat of the map: utils/slam_external.py:121-188 --------------------------------------------------------------
+ * prune_gaussians (:167-188) removes the Gaussians with sigmoid(logit_opacity) < removal threshold (and, past
+ * `remove_big_after`, those with max_c exp(log_scale_c) > 0.1 * scene_radius) from EVERY per-Gaussian tensor: the six
+ * parameters, their two Adam moments each, and the bookkeeping vectors (remove_points, :139-165) — ~22 boolean-mask
+ * gathers, each with its own nonzero() and host sync.  cat_params_to_optimizer (:121-137) appends the densified Gaussians to
+ * the same tensors, zeros for the Adam moments.  Here both are ONE order-preserving row compaction over a table of tensors:
+ *   hsr_prune_mask           the keep mask of :175-180 + its scan (the compaction's offsets) + the kept count;
+ *   hsr_compact_append_rows  for every table: dst[rank(i)] = src[i] for kept rows i (source order, as tensor[to_keep]), then
+ *                            the n_append new rows (table.append, or zeros when NULL) behind them.
+ * The caller allocates dst with room for P + n_append rows and narrows it to *out_rows afterwards (one read-back). */
+#define HSR_MAX_ROW_TABLES 40
+typedef struct hsr_row_table {
+    const float* src;      /* [P, cols] */
+    const float* append;   /* [n_append, cols] or NULL = zeros */
+    float* dst;            /* [>= kept + n_append, cols] */
+    int cols;
+} hsr_row_table;
+
+size_t hsr_compact_scratch_bytes(int P);
+
+/* out_keep: uint8[P] (1 = keep); out_kept: int[1].  log_scales is [P,S] (S = 1 isotropic, 3 anisotropic);
+ * big_world_threshold <= 0 switches the size test off (iter < remove_big_after).  `scratch` afterwards holds the scanned block
+ * counts hsr_compact_append_rows needs: pass the same scratch and keep_is_scanned = 1. */
+int hsr_prune_mask(int P, int S, const float* logit_opacities, const float* log_scales, float removal_opacity_threshold,
+                   float big_world_threshold, uint8_t* out_keep, int* out_kept, char* scratch, size_t scratch_bytes, void* stream);
+
+/* keep == NULL: every row is kept (pure concat).  keep_is_scanned: `scratch` and *out_rows come from hsr_prune_mask on the same
+ * mask.  out_rows (int[1], device): kept + n_append.  At most HSR_MAX_ROW_TABLES tables; `tables` is a HOST array. */
+int hsr_compact_append_rows(int P, const uint8_t* keep, int keep_is_scanned, int n_tables, const hsr_row_table* tables, int n_append,
+                            int* out_rows, char* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

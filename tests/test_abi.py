@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
             "hsr_required_geometry_bytes", "hsr_required_image_bytes", "hsr_required_binning_bytes", "hsr_last_error",
             "hsr_version", "hsr_get_state_layout", "hsr_profile_enable", "hsr_profile_read", "hsr_stage_name",
             "hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes",
-            "hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes", "hsr_densify_frame", "hsr_densify_scratch_bytes"} <= set(protos)
+            "hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes", "hsr_densify_frame", "hsr_densify_scratch_bytes",
+            "hsr_prune_mask", "hsr_compact_append_rows", "hsr_compact_scratch_bytes"} <= set(protos)
     lib = C.CDLL(_C._LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), "libhsr_rast.so does not export %s" % name
@@ -52,6 +53,10 @@ def test_ctypes_signatures_match_header():
     from hsr_utils import densify
     for name in ("hsr_densify_frame", "hsr_densify_scratch_bytes"):
         fn = getattr(densify._lib, name)
+        assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
+    from hsr_utils import slam_external
+    for name in ("hsr_prune_mask", "hsr_compact_append_rows", "hsr_compact_scratch_bytes"):
+        fn = getattr(slam_external._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
     from hsr_utils import losses
     for name in ("hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes"):

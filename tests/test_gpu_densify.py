@@ -67,3 +67,167 @@ def test_add_new_gaussians_semantic_grows_the_map_where_nothing_was_rendered():
     for k in ("rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales", "semantic"):
         assert params[k].shape[0] == n1 and isinstance(params[k], torch.nn.Parameter) and params[k].requires_grad
     assert variables["means2D_gradient_accum"].shape == (n1,) and variables["denom"].shape == (n1,)
+
+
+def _half_map(W, H, K, P, semantic=True, scales_cols=1):
+    from hsr_utils import setup_camera, make_scene
+    kmat = np.array([[150.0, 0, 79.5], [0, 150.0, 59.5], [0, 0, 1]])
+    cam = setup_camera(W, H, kmat, np.eye(4), device="cuda")
+    sc = make_scene(P, W, H, K, kmat, seed=4, scale_mult=3.0)
+    keep = sc["means3D"][:, 0] < 0                                            # a map that only covers the left half
+    params = {"means3D": sc["means3D"][keep], "unnorm_rotations": sc["rotations"][keep],
+              "logit_opacities": torch.full((int(keep.sum()), 1), 4.0), "log_scales": sc["scales"][keep][:, :scales_cols].log(),
+              "rgb_colors": sc["colors_precomp"][keep]}
+    if semantic:
+        params["semantic"] = sc["semantics_precomp"][keep]
+    params = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in params.items()}
+    params["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0]).view(1, 4, 1).repeat(1, 1, 2).cuda())
+    params["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 2).cuda())
+    n0 = params["means3D"].shape[0]
+    variables = {"timestep": torch.zeros(n0, device="cuda")}
+    curr = {"cam": cam, "w2c": torch.eye(4, device="cuda"), "depth": torch.full((1, H, W), 2.0, device="cuda"),
+            "im": torch.rand(3, H, W, device="cuda"), "intrinsics": torch.tensor(kmat, dtype=torch.float32)}
+    return params, variables, curr, n0
+
+
+def _torch_mask(final_opacity, rendered_depth, gt_depth, sil_thres):
+    """scripts/hierslam.py:1317-1329 / :1225-1236 + :1248-1249 / :1337-1338 with torch CPU ops"""
+    sil, rd, gt = final_opacity.cpu(), rendered_depth.cpu(), gt_depth.cpu()
+    depth_error = torch.abs(gt - rd) * (gt > 0)
+    m = (sil < sil_thres) | ((rd > gt) * (depth_error > 50 * depth_error.median()))
+    return (m.reshape(-1) & (gt > 0).reshape(-1)).numpy()
+
+
+@pytest.mark.parametrize("variant", ["semantic_newrender", "newtest_isotropic", "newtest_anisotropic"])
+def test_the_densify_functions_the_mapping_loop_calls(variant):
+    """add_new_gaussians_semantic_newrender (scripts/hierslam.py:1307-1352, called :1949) and add_new_gaussians_newtest
+    (:1214-1262, called :1945): the silhouette is the FINAL OPACITY of one no-grad render with the semantic / plain
+    rasterizer.  The selected pixels must equal the reference's mask expressions evaluated with torch CPU ops on the same
+    rendered maps — bit for bit — and the map must grow by exactly those pixels, in row-major order."""
+    from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizer_semantic
+    from hsr_utils import densify as D, slam_helpers as SH
+    W, H, K, P = 160, 120, 6, 3000
+    semantic = variant == "semantic_newrender"
+    params, variables, curr, n0 = _half_map(W, H, K, P, semantic=semantic, scales_cols=3 if variant.endswith("anisotropic") else 1)
+    curr["depth"][0, :10] = 0.0                                               # invalid depth rows are never densified
+    tg = SH.transform_to_frame(params, 1, gaussians_grad=False, camera_grad=False)
+    with torch.no_grad():
+        if semantic:
+            outs = GaussianRasterizer_semantic(curr["cam"])(**SH.transformed_params2rendervar_semantic(params, tg))
+            depth, final_opacity = outs[3], outs[5]
+        else:
+            outs = GaussianRasterizer(curr["cam"])(**SH.transformed_params2rendervar(params, tg))
+            depth, final_opacity = outs[2], outs[4]
+    expect = _torch_mask(final_opacity[0], depth[0], curr["depth"][0], 0.5)
+    if semantic:
+        params, variables = D.add_new_gaussians_semantic_newrender(params, variables, curr, 0.5, 1, "projective", K)
+    else:
+        dist = "anisotropic" if variant.endswith("anisotropic") else "isotropic"
+        params, variables = D.add_new_gaussians_newtest(params, variables, curr, 0.5, 1, "projective", dist)
+    n1 = params["means3D"].shape[0]
+    assert 0 < expect.sum() < expect.size and n1 - n0 == int(expect.sum())
+    # the new points ARE the back-projection of the selected pixels, in row-major order (get_pointcloud, :144-194)
+    ys, xs = np.nonzero(expect.reshape(H, W))
+    z = curr["depth"][0].cpu().numpy()[ys, xs]
+    exp_xyz = np.stack([(xs - 79.5) / 150.0 * z, (ys - 59.5) / 150.0 * z, z], 1)
+    np.testing.assert_allclose(params["means3D"][n0:].detach().cpu().numpy(), exp_xyz, rtol=1e-5, atol=1e-6)
+    exp_rgb = curr["im"].permute(1, 2, 0).reshape(-1, 3).cpu().numpy()[expect]
+    np.testing.assert_array_equal(params["rgb_colors"][n0:].detach().cpu().numpy(), exp_rgb)
+    exp_ls = np.log(np.sqrt((z / 150.0) ** 2))
+    got_ls = params["log_scales"][n0:].detach().cpu().numpy()
+    assert got_ls.shape == (n1 - n0, 3 if variant.endswith("anisotropic") else 1)
+    np.testing.assert_allclose(got_ls, np.repeat(exp_ls[:, None], got_ls.shape[1], 1), rtol=1e-5, atol=1e-6)
+    assert (variables["timestep"][n0:] == 1).all() and variables["denom"].shape == (n1,)
+    assert ("semantic" in params) == semantic and (not semantic or params["semantic"].shape == (n1, K))
+    with pytest.raises(ValueError):
+        D.add_new_gaussians_newtest(params, variables, curr, 0.5, 1, "projective", "isotropic", flag_use_render=2)
+
+
+# ---- prune / concat: pinned by the REFERENCE's own outputs (tests/golden/densify_prune_concat.npz, generated by
+# tests/golden/make_densify_golden.py from utils/slam_external.py's prune_gaussians and cat_params_to_optimizer) ------------
+GOLD = os.path.join(ROOT, "tests", "golden", "densify_prune_concat.npz")
+KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales", "semantic")
+
+
+def _load_state(z, prefix):
+    """params (cuda Parameters), variables, Adam optimizer whose state is the fixture's"""
+    params = {k: torch.nn.Parameter(torch.tensor(z["%s/param/%s" % (prefix, k)]).cuda()) for k in KEYS + ("cam_unnorm_rots", "cam_trans")}
+    opt = torch.optim.Adam([{"params": [v], "name": k, "lr": 1e-2} for k, v in params.items()])
+    for k, v in params.items():
+        if "%s/exp_avg/%s" % (prefix, k) in z:
+            opt.state[v] = {"step": torch.tensor(float(z["%s/step/%s" % (prefix, k)])),
+                            "exp_avg": torch.tensor(z["%s/exp_avg/%s" % (prefix, k)]).cuda(),
+                            "exp_avg_sq": torch.tensor(z["%s/exp_avg_sq/%s" % (prefix, k)]).cuda()}
+    variables = {k.split("/")[-1]: torch.tensor(z[k]).cuda() for k in z.files if k.startswith(prefix + "/var/")}
+    return params, variables, opt
+
+
+def _assert_state_equals(z, prefix, params, variables, opt):
+    for k in KEYS + ("cam_unnorm_rots", "cam_trans"):
+        exp = z["%s/param/%s" % (prefix, k)]
+        assert isinstance(params[k], torch.nn.Parameter) and params[k].requires_grad
+        assert np.array_equal(params[k].detach().cpu().numpy(), exp), k             # rows in order, bit for bit
+        group = [g for g in opt.param_groups if g["name"] == k][0]
+        assert group["params"][0] is params[k]
+        st = opt.state.get(params[k], None)
+        if "%s/exp_avg/%s" % (prefix, k) in z:
+            assert np.array_equal(st["exp_avg"].cpu().numpy(), z["%s/exp_avg/%s" % (prefix, k)]), k
+            assert np.array_equal(st["exp_avg_sq"].cpu().numpy(), z["%s/exp_avg_sq/%s" % (prefix, k)]), k
+            assert float(st["step"]) == float(z["%s/step/%s" % (prefix, k)])
+        else:
+            assert not st
+    for k in z.files:
+        if k.startswith(prefix + "/var/"):
+            assert np.array_equal(variables[k.split("/")[-1]].cpu().numpy(), z[k]), k
+    assert len(opt.state) == sum(1 for k in params if "%s/exp_avg/%s" % (prefix, k) in z)   # no orphaned state entries
+
+
+@pytest.mark.parametrize("case", ["prune_iter0", "prune_final_aniso", "prune_no_big", "prune_not_this_iter", "prune_reset_opacities"])
+def test_prune_gaussians_matches_the_reference_outputs(case):
+    from hsr_utils import slam_external as SE
+    z = np.load(GOLD, allow_pickle=False)
+    params, variables, opt = _load_state(z, case + "/in")
+    pd = {k.split("/")[-1]: float(z[k]) for k in z.files if k.startswith(case + "/prune_dict/")}
+    pd["reset_opacities"] = bool(pd["reset_opacities"])
+    n_in = params["means3D"].shape[0]
+    params, variables = SE.prune_gaussians(params, variables, opt, int(z[case + "/iter"]), pd)
+    _assert_state_equals(z, case + "/out", params, variables, opt)
+    n_out = z[case + "/out/param/means3D"].shape[0]
+    assert (n_out < n_in) == (case not in ("prune_not_this_iter",))
+    # the pruned map still trains: one more Adam step through the re-keyed state
+    (params["means3D"].sum() + params["semantic"].sum()).backward()
+    opt.step()
+
+
+@pytest.mark.parametrize("case", ["cat_small", "cat_empty_map", "cat_nothing_new"])
+def test_cat_params_to_optimizer_matches_the_reference_outputs(case):
+    from hsr_utils import slam_external as SE
+    z = np.load(GOLD, allow_pickle=False)
+    params, variables, opt = _load_state(z, case + "/in")
+    new = {k: torch.tensor(z["%s/new/%s" % (case, k)]).cuda() for k in KEYS}
+    params = SE.cat_params_to_optimizer(new, params, opt)
+    _assert_state_equals(z, case + "/out", params, {}, opt)
+
+
+def test_remove_points_with_a_caller_mask_and_bad_input():
+    from hsr_utils import slam_external as SE
+    z = np.load(GOLD, allow_pickle=False)
+    params, variables, opt = _load_state(z, "prune_iter0/in")
+    P = params["means3D"].shape[0]
+    g = torch.Generator().manual_seed(5)
+    to_remove = (torch.rand(P, generator=g) < 0.37).cuda()
+    exp = {k: params[k].detach()[~to_remove].cpu().numpy() for k in KEYS}
+    exp_m = {k: opt.state[params[k]]["exp_avg"][~to_remove].cpu().numpy() for k in KEYS}
+    exp_v = {k: variables[k][~to_remove].cpu().numpy() for k in SE.VARIABLE_KEYS}
+    params, variables = SE.remove_points(to_remove, params, variables, opt)
+    for k in KEYS:
+        assert np.array_equal(params[k].detach().cpu().numpy(), exp[k]) and np.array_equal(opt.state[params[k]]["exp_avg"].cpu().numpy(), exp_m[k])
+    for k in SE.VARIABLE_KEYS:
+        assert np.array_equal(variables[k].cpu().numpy(), exp_v[k])
+    assert params["cam_trans"].shape == (1, 3, 5)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        SE.compact_append([torch.zeros(4, 3)], keep=None)
+    # nothing kept / everything kept
+    all_gone = torch.ones(params["means3D"].shape[0], dtype=torch.bool, device="cuda")
+    p2, v2 = SE.remove_points(all_gone, params, variables, opt)
+    assert p2["means3D"].shape == (0, 3) and v2["timestep"].shape == (0,)
