@@ -25,6 +25,8 @@
 // that design: 1.03 ms, of which 0.68 ms LDS atomics).
 #include "hsr_tile_common.h"
 #include "hsr_wave_reduce.h"
+#include <stdlib.h>
+#include <string.h>
 
 #ifdef HSR_TRACE
 // Diagnostic build only (make -C hier-slam_amd/csrc trace -> libhsr_rast_trace.so, tools/trace_bwd.py): per-wave cycle counts of
@@ -580,9 +582,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
 // pass adds the five direct sums and the seven butterfly values, a SEM pass only re-derives alpha and T and feeds the panel.
 // 16 * NG >= ns + (BASE ? 5 : 0).
 template <int NG, bool BASE, int BATCH>
-__global__ void __launch_bounds__(256, NG <= 2 ? 4 : 3) render_bwd_subw_kernel(RenderBwdArgs a, int c0, int ns)
+__global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_bwd_subw_kernel(RenderBwdArgs a, int c0, int ns)
 {
-    static_assert(NG <= 4, "at most 64 channels per pass");
+    static_assert(NG <= 7, "at most 112 channels per pass (the B operand lives in 16 * NG registers)");
     static_assert(BATCH <= 256, "batch slots are bytes");
     __shared__ float4 s_geo[BATCH];
     __shared__ float2 s_co[BATCH];
@@ -873,7 +875,10 @@ void launch_subw_pass(const RenderBwdArgs& a, int c0, int ns, dim3 grid, hipStre
     if (groups <= 1) render_bwd_subw_kernel<1, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
     else if (groups == 2) render_bwd_subw_kernel<2, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
     else if (groups == 3) render_bwd_subw_kernel<3, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
-    else render_bwd_subw_kernel<4, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 4) render_bwd_subw_kernel<4, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 5) render_bwd_subw_kernel<5, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 6) render_bwd_subw_kernel<6, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
+    else render_bwd_subw_kernel<7, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
 }
 }  // namespace
 
@@ -891,7 +896,12 @@ int hsr_launch_render_backward_subw(const RenderBwdArgs& a, hipStream_t stream)
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
     const dim3 grid(hsr_tile_grid(tiles));
     const int K = a.K;
-    const int first = K < 59 ? K : 59;
+    // One pass while the B operand (16 registers per 16 columns) fits two waves per SIMD: K + 5 <= 112 columns.  Every pass
+    // re-derives alpha and T for every (pixel, splat) pair, and that — not the matrix-core work, which is the same in total —
+    // is most of a pass: K = 74 in ONE pass of 80 columns at 2 waves per SIMD instead of 64 + 22 columns at 3 and 4.
+    static const char* e_pass = getenv("HSR_BWD_WIDE_PASS");   // kernel-family selector (parity-tested): "split" = 64-column passes
+    const bool split = e_pass && !strcmp(e_pass, "split");
+    const int first = split ? (K < 59 ? K : 59) : (K < 107 ? K : 107);
     launch_subw_pass<true>(a, 0, first, grid, stream);
     for (int c0 = first; c0 < K; c0 += 64) launch_subw_pass<false>(a, c0, K - c0 < 64 ? K - c0 : 64, grid, stream);
     return HSR_OK;

@@ -183,6 +183,20 @@ def test_parity_alternate_kernels(impl):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_parity_wide_tree_kernel_selectors():
+    """wide trees (K > 27) default to ONE backward pass of up to 112 columns at two waves per SIMD; HSR_BWD_WIDE_PASS=split
+    selects the earlier 64-column passes (what K + 5 > 112 still takes): same results, parity cases in a child process"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
+            "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
+            "for n in ('generic_k40_two_chunks','large_tree_k74','flat_k102','odd_k33','odd_k75_ragged','k124_widest_single_pass','k130_chunked','wide_deep_tiles_k76')];print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (dict(HSR_BWD_WIDE_PASS="split"),):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_ctypes_glue_matches_too():
     """The four rasterize entry points run through the compiled torch glue (diff_gaussian_rasterization._hsr_torch) when it is
     built; HSR_GLUE=ctypes selects the pure-Python glue over the same C ABI.  Parity cases through that one, in a child process."""
