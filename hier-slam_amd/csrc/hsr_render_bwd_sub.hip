@@ -901,8 +901,11 @@ int hsr_launch_render_backward_subw(const RenderBwdArgs& a, hipStream_t stream)
     // is most of a pass: K = 74 in ONE pass of 80 columns at 2 waves per SIMD instead of 64 + 22 columns at 3 and 4.
     static const char* e_pass = getenv("HSR_BWD_WIDE_PASS");   // kernel-family selector (parity-tested): "split" = 64-column passes
     const bool split = e_pass && !strcmp(e_pass, "split");
+    // (Other splits were measured too, tools/wide_split_sweep.sh on 500k Gaussians: every extra pass costs ~0.3-0.5 ms whatever its
+    // width — K = 74: one pass 0.62 ms, 27 + 47 channels 0.89 ms, 43 + 31 0.82 ms; K = 102: 0.79 vs 1.16-1.34 ms.)
     const int first = split ? (K < 59 ? K : 59) : (K < 107 ? K : 107);
+    const int chunk = 64;
     launch_subw_pass<true>(a, 0, first, grid, stream);
-    for (int c0 = first; c0 < K; c0 += 64) launch_subw_pass<false>(a, c0, K - c0 < 64 ? K - c0 : 64, grid, stream);
+    for (int c0 = first; c0 < K; c0 += chunk) launch_subw_pass<false>(a, c0, K - c0 < chunk ? K - c0 : chunk, grid, stream);
     return HSR_OK;
 }
