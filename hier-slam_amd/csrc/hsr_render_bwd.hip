@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
         if (t < cnt) {
             // slot 0 is the farthest entry of this batch (list position hi-1), like the reference's
             // reverse staging (backward.cu:562, :771)
-            qmask = quadrant_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
+            qmask = quadrant_mask_exact(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
             s_id[t] = id_cur;
             s_geo[t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
             s_co[t] = make_float2((-0.5f * HSR_LOG2E) * p_co.z, p_co.w);

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and not f.startswith("loss_")))
+@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and not f.startswith(("loss_", "densify_"))))
 def test_hip_matches_golden(name):
     z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
     cam = dict(image_height=int(z["H"]), image_width=int(z["W"]), tanfovx=float(z["tanfovx"]), tanfovy=float(z["tanfovy"]),
