@@ -169,21 +169,20 @@ __device__ __forceinline__ uint32_t subblock_mask(float x, float y, float cx, fl
     const float atau = cx * tau, nb = -cy;
     const float rx = x - tile_x0, ry = y - tile_y0;     // splat centre, tile-relative
     uint32_t m = 0u;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
+    float ry_hi = ry;                                   // ry - 4 r
+#pragma nounroll                                        // rolled on purpose: unrolled, the four rows' temporaries spill in the backward
+    for (int r = 0; r < 4; r++, ry_hi -= 4.0f) {
         // the row's slab of dy = centre - pixel centre, cut to E's own extent
-        const float lo = fmaxf(ry - (4.0f * r + 3.0f), -hy), hi = fminf(ry - 4.0f * r, hy);
+        const float lo = fmaxf(ry_hi - 3.0f, -hy), hi = fminf(ry_hi, hy);
         const float dyu = __builtin_amdgcn_fmed3f(dyp, lo, hi), dyl = __builtin_amdgcn_fmed3f(-dyp, lo, hi);
         const float xmax = fmaf(nb, dyu, sqrtf(fmaxf(fmaf(-det * dyu, dyu, atau), 0.0f))) * inv_a + 0.02f;
         const float xmin = fmaf(nb, dyl, -sqrtf(fmaxf(fmaf(-det * dyl, dyl, atau), 0.0f))) * inv_a - 0.02f;
-        const bool row_on = lo <= hi;
+        // bit of sub-block (column c, row r): wave = (r>>1)*2 + (c>>1), gq = (r&1)*2 + (c&1): the row's columns sit at bits 0, 1, 4, 5
+        uint32_t rb = 0u;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            // the sub-block's dx interval is [rx - (4c + 3), rx - 4c]
-            const bool on = row_on && (rx - (4.0f * c + 3.0f)) <= xmax && (rx - 4.0f * c) >= xmin;
-            // bit of sub-block (column c, row r): wave = (r>>1)*2 + (c>>1), gq = (r&1)*2 + (c&1)
-            m |= (uint32_t)on << (8 * (r >> 1) + 4 * (c >> 1) + 2 * (r & 1) + (c & 1));
-        }
+        for (int c = 0; c < 4; c++)   // the sub-block's dx interval is [rx - (4c + 3), rx - 4c]
+            rb |= (uint32_t)((rx - (4.0f * c + 3.0f)) <= xmax && (rx - 4.0f * c) >= xmin) << (4 * (c >> 1) + (c & 1));
+        if (lo <= hi) m |= rb << (8 * (r >> 1) + 2 * (r & 1));
     }
     return m;
 }
