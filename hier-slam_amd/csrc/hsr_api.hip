@@ -678,16 +678,15 @@ size_t hsr_carve_img(char* base, int W, int H, ImgState* out)
 }
 size_t hsr_carve_bin(char* base, int R, BinState* out)
 {
-    char* p = base;
+    // ONE layout rule for the binning buffer: hsr_bin_resolve (hsr_common.h), which the speculative kernels also evaluate on the
+    // device from num_rendered.  It aligns each array from the real address, so the size query runs it from a 256-aligned origin.
     BinState b;
-    const size_t Rn = (size_t)(R > 0 ? R : 1);
-    take(p, b.keys_unsorted, Rn);
-    take(p, b.keys, Rn);
-    take(p, b.vals_unsorted, Rn);
-    take(p, b.vals, Rn);
-    take(p, b.hist, hsr_sort_hist_entries(R));
+    char* origin = base ? base : reinterpret_cast<char*>(uintptr_t(256));
+    const BinDevRef ref{origin, nullptr, ~size_t(0) >> 1};
+    hsr_bin_resolve(ref, (uint32_t)(R > 0 ? R : 0), &b);
     if (out) *out = b;
-    return (size_t)(p - base);
+    const uint32_t Rn = (uint32_t)(R > 0 ? R : 0);
+    return (size_t)(reinterpret_cast<char*>(b.hist + hsr_sort_hist_entries_inline(Rn)) - origin);
 }
 
 extern "C" {

@@ -170,6 +170,9 @@ class TransformedGaussians(dict):
                                 p['cam_trans'], w2c, self._time_idx, rot_source, self._gaussians_grad, self._camera_grad)
         bundle = dict(zip(("means3D", "unnorm_rotations", "rotations", "opacities", "scales", "depth_sil"), outs))
         bundle["rot_source"], bundle["has_sil"] = rot_source, w2c is not None
+        # which w2c the depth / silhouette plane was formed with: a later request with ANOTHER matrix (or the same tensor modified
+        # in place) must not be served from this bundle
+        bundle["w2c_key"] = None if w2c is None else (id(w2c), int(getattr(w2c, "_version", 0)))
         if self._bundle is None:
             self._bundle = bundle
             dict.__setitem__(self, 'means3D', bundle['means3D'])
@@ -178,7 +181,8 @@ class TransformedGaussians(dict):
 
     def bundle(self, rot_source, w2c=None):
         b = self._bundle
-        if b is not None and b["rot_source"] == rot_source and (w2c is None or b["has_sil"]):
+        if b is not None and b["rot_source"] == rot_source and (
+                w2c is None or (b["has_sil"] and b["w2c_key"] == (id(w2c), int(getattr(w2c, "_version", 0))))):
             return b
         return self._run(rot_source, w2c)
 

@@ -192,3 +192,22 @@ def test_prep_chained_into_rasterizer_matches_eager_chain():
     _close("means2D.grad", m2a.cpu().numpy(), m2b.cpu().numpy(), 1e-5)
     for k in ga:
         _close(k + ".grad", ga[k].cpu().numpy(), gb[k].cpu().numpy(), 1e-4)
+
+
+def test_depth_silhouette_bundle_is_not_reused_for_another_w2c():
+    """a TransformedGaussians caches the bundle of its first launch; a second depth+silhouette request with a
+    DIFFERENT world-to-camera matrix (or the same tensor changed in place) must be recomputed, not served from the cache."""
+    from hsr_utils import slam_helpers as SH
+    inp, t = _params(500, 1)
+    tg = SH.transform_to_frame(t, 2, gaussians_grad=False, camera_grad=False)
+    w_a = torch.eye(4, device="cuda")
+    w_b = torch.eye(4, device="cuda"); w_b[2, 3] = 0.75
+    rv_a = SH.transformed_params2depthplussilhouette(t, w_a, tg)
+    rv_a2 = SH.transformed_params2depthplussilhouette(t, w_a, tg)
+    assert rv_a2["colors_precomp"] is rv_a["colors_precomp"]                  # same matrix: the cached launch serves it
+    rv_b = SH.transformed_params2depthplussilhouette(t, w_b, tg)
+    d_a, d_b = rv_a["colors_precomp"][:, 0], rv_b["colors_precomp"][:, 0]
+    assert torch.allclose(d_b, d_a + 0.75, atol=1e-5)                          # depth moved with the camera
+    w_a[2, 3] = -0.25                                                          # in-place edit of the first matrix
+    rv_c = SH.transformed_params2depthplussilhouette(t, w_a, tg)
+    assert torch.allclose(rv_c["colors_precomp"][:, 0], d_a - 0.25, atol=1e-5)
