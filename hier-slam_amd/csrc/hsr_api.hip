@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/hsr_rasterizer.h"
@@ -684,9 +685,14 @@ size_t hsr_carve_bin(char* base, int R, BinState* out)
     char* origin = base ? base : reinterpret_cast<char*>(uintptr_t(256));
     const BinDevRef ref{origin, nullptr, ~size_t(0) >> 1};
     hsr_bin_resolve(ref, (uint32_t)(R > 0 ? R : 0), &b);
-    if (out) *out = b;
     const uint32_t Rn = (uint32_t)(R > 0 ? R : 0);
-    return (size_t)(reinterpret_cast<char*>(b.hist + hsr_sort_hist_entries_inline(Rn)) - origin);
+    const size_t bytes = (size_t)(reinterpret_cast<char*>(b.hist + hsr_sort_hist_entries_inline(Rn)) - origin);
+    if (!base) {   // layout query: offsets from a NULL base, as hsr_get_state_layout reports them
+        auto rebase = [&](auto*& q) { q = reinterpret_cast<std::remove_reference_t<decltype(q)>>(reinterpret_cast<char*>(q) - 256); };
+        rebase(b.keys_unsorted); rebase(b.keys); rebase(b.vals_unsorted); rebase(b.vals); rebase(b.hist);
+    }
+    if (out) *out = b;
+    return bytes;
 }
 
 extern "C" {
