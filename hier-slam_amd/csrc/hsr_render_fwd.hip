@@ -46,11 +46,11 @@ struct FwdCfg {
 // are read for real — L2 hits — right before they are staged.  K = 74: 238 -> ~160 registers, i.e. three waves per SIMD instead of
 // two, in a kernel whose blend loop is bound by instruction issue.
 template <int KC, bool BASE, bool MASK, bool ALIGNED, bool SUB = false, bool PF = false>
-__global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? 3 : 1)) render_fwd_kernel(RenderFwdArgs a, int c0)
+__global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ? 4 : 3) : 1)) render_fwd_kernel(RenderFwdArgs a, int c0)
 {
     // SUB: 240 splats per batch keep the 16 lists + records of K = 26 under 40 KB (four workgroups per CU).  (PF at K = 26 with
     // 184-splat batches and five waves per SIMD was measured too: 96 registers with 5 spills, 0.174 vs 0.165 ms — not taken.)
-    constexpr int BATCH = (SUB && KC <= 32) ? 240 : FwdCfg<KC>::BATCH;
+    constexpr int BATCH = (SUB && KC <= 32) ? (KC > 26 ? 200 : 240) : FwdCfg<KC>::BATCH;   // KC = 32: 200 x 176 B + lists < 40 KB
     // per staged splat: a 32-byte record { x, y, A, B | C, opacity, r, g } (pre-scaled conic, see hsr_tile_common.h) — all the
     // alpha test needs, in two 16-byte reads at one address — and a feature row { s0 .. s(KC-1), b, depth } whose 16-byte reads
     // pair up with the packed FMAs (blue and depth ride in the row's padding at K = 26): one LDS read and one address
@@ -175,34 +175,46 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? 3 : 1)) ren
                         : quadrant_mask_exact(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
             s_rec[2 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
             s_rec[2 * t + 1] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, p_r, p_g);
-            float rv[RW];
+            float4* row = &s_row[t * (RW / 4)];
             if (PF) {
                 // the touches of this batch have landed long ago (they were issued a whole batch of blending earlier): consume them
-                // so that they stay real loads, then fetch the row — L2 hits — straight into the staging registers
+                // so that they stay real loads, then fetch the row — L2 hits — and stage it 32 floats at a time (the whole row in
+                // flight at once would need KC more registers than the blend loop leaves)
 #pragma unroll
                 for (int c = 0; c < NPF; c++) pf_sink += pf_t[c];
-                if (ALIGNED) {
-                    const float2* grow = reinterpret_cast<const float2*>(a.semantics + (size_t)id_cur * (size_t)KC);
+                const float* grow = a.semantics + (size_t)id_cur * (size_t)a.K + c0;
 #pragma unroll
-                    for (int q = 0; q < KC / 2; q++) {
-                        const float2 v = grow[q];
-                        rv[2 * q] = v.x;
-                        rv[2 * q + 1] = v.y;
+                for (int g0 = 0; g0 < RW; g0 += 32) {
+                    float rv[32];
+#pragma unroll
+                    for (int c = 0; c < 32; c++) {
+                        const int ch = g0 + c;
+                        if (ch < KC) {
+                            if (ALIGNED) {
+                                if ((c & 1) == 0) {
+                                    const float2 v = reinterpret_cast<const float2*>(grow)[ch / 2];
+                                    rv[c] = v.x;
+                                    if (c + 1 < 32) rv[c + 1] = v.y;
+                                }
+                            } else {
+                                rv[c] = (c0 + ch < a.K) ? grow[ch] : 0.f;
+                            }
+                        } else if (ch < RW) {
+                            rv[c] = ch == KC ? p_b : (ch == KC + 1 ? p_d : 0.f);
+                        }
                     }
-                } else {
-                    const float* grow = a.semantics + (size_t)id_cur * (size_t)a.K + c0;
 #pragma unroll
-                    for (int c = 0; c < KC; c++) rv[c] = (c0 + c < a.K) ? grow[c] : 0.f;
+                    for (int q = 0; q < 8; q++)
+                        if (g0 / 4 + q < RW / 4) row[g0 / 4 + q] = make_float4(rv[4 * q], rv[4 * q + 1], rv[4 * q + 2], rv[4 * q + 3]);
+                    asm volatile("" ::: "memory");   // next group's loads stay behind this group's stores
                 }
-#pragma unroll
-                for (int c = KC; c < RW; c++) rv[c] = c == KC ? p_b : (c == KC + 1 ? p_d : 0.f);
             } else {
+                float rv[RW];
 #pragma unroll
                 for (int c = 0; c < RW; c++) rv[c] = c < KC ? p_sem[(c < KC && !PF) ? c : 0] : (c == KC ? p_b : (c == KC + 1 ? p_d : 0.f));
-            }
-            float4* row = &s_row[t * (RW / 4)];
 #pragma unroll
-            for (int q = 0; q < RW / 4; q++) row[q] = make_float4(rv[4 * q], rv[4 * q + 1], rv[4 * q + 2], rv[4 * q + 3]);
+                for (int q = 0; q < RW / 4; q++) row[q] = make_float4(rv[4 * q], rv[4 * q + 1], rv[4 * q + 2], rv[4 * q + 3]);
+            }
         }
         if (SUB) publish_subblock_lists(qmask, t, s_sublist, s_subcnt);
         else publish_quadrant_lists(qmask, t, s_list, s_lcnt);
@@ -384,6 +396,19 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     // K=33 0.41/0.59 ms, 60 0.43/0.62, 90 0.62/0.96, 102 0.70/1.16, 124 0.71/1.24 — and K=74 0.61/0.54, the one
     // width whose fused per-lane instantiation (222 registers, 2 waves/SIMD) still wins, so it keeps it (0.47 ms on
     // sub-block lists).
+    // Round 2: with the rows of the next batch touched into L2 instead of parked in registers (PF), the per-lane kernel on
+    // sub-block lists runs at three or four waves per SIMD up to 80 channels and beats the matrix-core kernel there (500k
+    // Gaussians: K = 32 0.41 -> see profiles/r02_fwd_generic_k.log); the matrix-core kernel keeps 81 <= K <= 124.
+    // HSR_FWD_IMPL=wide restores its old range (parity-tested).
+    static const bool prefer_wide = impl && !strcmp(impl, "wide");
+    const bool per_lane_pf = !force_valu && !prefer_wide && a.K >= 27 && a.K <= 80 && a.K != 74;
+    if (per_lane_pf) {
+        if (a.K <= 32) render_fwd_kernel<32, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
+        else if (a.K <= 48) render_fwd_kernel<48, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
+        else if (a.K <= 64) render_fwd_kernel<64, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
+        else render_fwd_kernel<80, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
+        return HSR_OK;
+    }
     if (!force_valu && a.K != 74 && hsr_launch_render_forward_wide(a, stream)) return HSR_OK;
     if (!force_valu) {
         switch (a.K) {

@@ -192,7 +192,8 @@ def test_parity_wide_tree_kernel_selectors():
             "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
             "for n in ('generic_k40_two_chunks','large_tree_k74','flat_k102','odd_k33','odd_k75_ragged','k124_widest_single_pass','k130_chunked','wide_deep_tiles_k76')];print('ok')")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in (dict(HSR_BWD_WIDE_PASS="split"), dict(HSR_FWD_PF="0")):   # + the K = 74 forward with its rows parked in registers
+    # + the K = 74 forward with its rows parked in registers, + the matrix-core forward in its round-1 range (29..124)
+    for extra in (dict(HSR_BWD_WIDE_PASS="split"), dict(HSR_FWD_PF="0"), dict(HSR_FWD_IMPL="wide")):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
 
