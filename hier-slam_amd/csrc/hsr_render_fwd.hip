@@ -27,6 +27,21 @@
 
 #include "hsr_tile_common.h"
 
+#ifdef HSR_TRACE
+// Diagnostic build only (make -C hier-slam_amd/csrc trace -> libhsr_rast_trace.so, tools/trace_fwd.py): per-wave shader-cycle counts of
+// the phases of render_fwd_kernel (sub-block variant).  Never in the product.
+__device__ unsigned long long g_hsr_trace_fwd[16384 * 8];
+extern "C" int hsr_debug_read_trace_fwd(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hsr_trace_fwd), sizeof(unsigned long long) * (size_t)n);
+}
+#define TRF_NOW() clock64()
+#define TRF_ADD(acc, t0) (acc) += (unsigned long long)(clock64() - (t0))
+#else
+#define TRF_NOW() 0ll
+#define TRF_ADD(acc, t0) ((void)0)
+#endif
+
 namespace {
 
 template <int KC>
@@ -81,6 +96,11 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
     asm volatile("" : "+v"(pfx), "+v"(pfy));
     const float tile_x0 = (float)(tg.tx * HSR_TILE_X), tile_y0 = (float)(tg.ty * HSR_TILE_Y);
 
+    unsigned long long tr_bar = 0, tr_stage = 0, tr_blend = 0, tr_iters = 0, tr_pub = 0;
+    (void)tr_pub;
+    const long long tr_t0 = TRF_NOW();
+    long long tr_t1 = tr_t0;
+    (void)tr_bar; (void)tr_stage; (void)tr_blend; (void)tr_iters; (void)tr_t0; (void)tr_t1;
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
 
@@ -166,7 +186,13 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
     for (int start = 0; start < n; start += BATCH) {
         const bool wave_done = __ballot(!done) == 0ull;
         if ((t & 63) == 0) s_wdone[wv] = wave_done;
+        const long long tb0 = TRF_NOW();
+        (void)tb0;
         __syncthreads();  // also: everyone has finished reading the previous batch
+        TRF_ADD(tr_bar, tb0);
+        if (start == 0) tr_t1 = TRF_NOW();   // end of the prologue: ids, first records and the first barrier
+        const long long ts0 = TRF_NOW();
+        (void)ts0;
         if (s_wdone[0] & s_wdone[1] & s_wdone[2] & s_wdone[3]) break;
         const int cnt = min(BATCH, n - start);
         uint32_t qmask = 0u;
@@ -216,9 +242,18 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
                 for (int q = 0; q < RW / 4; q++) row[q] = make_float4(rv[4 * q], rv[4 * q + 1], rv[4 * q + 2], rv[4 * q + 3]);
             }
         }
+        const long long tp0 = TRF_NOW();
+        (void)tp0;
         if (SUB) publish_subblock_lists(qmask, t, s_sublist, s_subcnt);
         else publish_quadrant_lists(qmask, t, s_list, s_lcnt);
+        TRF_ADD(tr_pub, tp0);
+        TRF_ADD(tr_stage, ts0);
+        const long long tb1 = TRF_NOW();
+        (void)tb1;
         __syncthreads();
+        TRF_ADD(tr_bar, tb1);
+        const long long tl0 = TRF_NOW();
+        (void)tl0;
         // next batch's gathers go out now and land while this batch is blended
         load_record(start + BATCH);
         load_id(start + 2 * BATCH);
@@ -287,7 +322,11 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
                     T = test_T;
                     last_contributor = (uint32_t)(start + j + 1);
                 }
+#ifdef HSR_TRACE
+                tr_iters++;
+#endif
             }
+            TRF_ADD(tr_blend, tl0);
             continue;
         }
 
@@ -347,6 +386,9 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
     }
 
     if (PF && pf_sink == 1.2345678e-30f) T = pf_sink;   // never true for data that matters; keeps the touch loads alive
+#ifdef HSR_TRACE
+    const long long tr_t2 = clock64();   // end of the batch loop
+#endif
     if (inside) {
         const size_t pix_id = (size_t)a.W * (size_t)(int)pfy + (size_t)(int)pfx;
         if (BASE) {
@@ -367,6 +409,20 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
                 if (c0 + c < a.K) a.out_semantic[(size_t)(c0 + c) * N + pix_id] = S[c];
         }
     }
+#ifdef HSR_TRACE
+    if ((t & 63) == 0 && SUB) {
+        const int wid = tile * 4 + wv;
+        if (wid < 16384) {
+            unsigned long long* o = g_hsr_trace_fwd + (size_t)wid * 8;
+            o[0] = (unsigned long long)(clock64() - tr_t0);   // total
+            o[1] = (unsigned long long)(tr_t1 - tr_t0);       // prologue
+            o[2] = tr_bar; o[3] = tr_stage; o[4] = tr_blend;  // inside workgroup barriers / staging work / blend loops
+            o[5] = (unsigned long long)(clock64() - tr_t2);   // epilogue (output stores)
+            o[6] = tr_iters;
+            o[7] = tr_pub;                                    // of the staging work: publishing the sixteen sub-block lists
+        }
+    }
+#endif
 }
 
 }  // namespace
