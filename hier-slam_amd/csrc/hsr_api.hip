@@ -349,7 +349,11 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     ra.rec = g.rec;
     ra.final_T = im.final_T; ra.n_contrib = im.n_contrib; ra.median_pos = im.median_pos;
     ra.out_color = in.out_color; ra.out_semantic = in.out_semantic; ra.out_depth = in.out_depth;
-    ra.out_median_depth = in.out_median; ra.out_opacity = in.out_opacity; ra.out_mask = in.out_mask; ra.debug_flags = 0;
+    ra.out_median_depth = in.out_median; ra.out_opacity = in.out_opacity; ra.out_mask = in.out_mask;
+    {
+        static const int dbg = hsr_ablate_env("HSR_DEBUG_FLAGS") ? atoi(hsr_ablate_env("HSR_DEBUG_FLAGS")) : 0;
+        ra.debug_flags = dbg & 16;   // 0 in the product build; ablate build: bit 4 = no sub-block culling
+    }
     ra.bin = BinDevRef{nullptr, nullptr, 0};
     if (!in.semantic && !in.out_mask) {
         hsr_set_error("out_mask is NULL");

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
-            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
+            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
             qmask = (uint32_t)((mask & 0xFu) != 0u) | ((uint32_t)((mask & 0xF0u) != 0u) << 1) | ((uint32_t)((mask & 0xF00u) != 0u) << 2) |
                     ((uint32_t)((mask & 0xF000u) != 0u) << 3);
             s_mask[t] = (uint16_t)mask;
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
-            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
+            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
             qmask = (uint32_t)((mask & 0xFu) != 0u) | ((uint32_t)((mask & 0xF0u) != 0u) << 1) | ((uint32_t)((mask & 0xF00u) != 0u) << 2) |
                     ((uint32_t)((mask & 0xF000u) != 0u) << 3);
             s_mask[t] = (uint16_t)mask;
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
-            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
+            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
             qmask = (uint32_t)((mask & 0xFu) != 0u) | ((uint32_t)((mask & 0xF0u) != 0u) << 1) | ((uint32_t)((mask & 0xF00u) != 0u) << 2) |
                     ((uint32_t)((mask & 0xF000u) != 0u) << 3);
             s_mask[t] = (uint16_t)mask;

@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
         const int cnt = min(BATCH, n - start);
         uint32_t qmask = 0u;
         if (t < cnt) {
-            qmask = SUB ? subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0)
+            qmask = SUB ? subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16))
                         : quadrant_mask_exact(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
             s_rec[2 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
             s_rec[2 * t + 1] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, p_r, p_g);

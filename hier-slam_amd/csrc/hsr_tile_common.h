@@ -156,10 +156,11 @@ __device__ __forceinline__ TileGeom tile_geom_sub(int tile, int W, int H, int t)
 // would cost accuracy — the parity and fuzz suites compare every pixel with the oracle).  ~25 live registers: it is inlined
 // into the staging phase of kernels that sit at the 128-register step.
 __device__ __forceinline__ uint32_t subblock_mask(float x, float y, float cx, float cy, float cz, float opacity, float tile_x0,
-                                                  float tile_y0)
+                                                  float tile_y0, bool cull = true)
 {
     const float t255 = 255.0f * opacity;
     if (!(t255 >= 1.0f)) return 0u;
+    if (!cull) return 0xFFFFu;   // ablate build, HSR_DEBUG_FLAGS & 16: every sub-block visits every splat (tools/check_culling.py)
     const float tau = 2.0f * __logf(t255) * 1.002f + 0.02f;
     const float det = cx * cz - cy * cy;
     if (!(det > 0.0f) || !(cx > 0.0f) || !(cz > 0.0f)) return 0xFFFFu;

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Is the exact sub-block culling (hsr_tile_common.h: subblock_mask) conservative?  It may keep a sub-block in vain, it must never
+drop one in which some pixel reaches alpha >= 1/255.  With culling switched off (ablate build, HSR_DEBUG_FLAGS=16: every sub-block
+visits every splat of the tile) the per-pixel accumulation order is unchanged, so the forward outputs must be BIT-identical; the
+gradients agree to atomics-order noise.  Runs N seeded scenes (sizes, isotropic / anisotropic, splats from sub-pixel to screen-filling,
+opacities down to the 1/255 threshold) in two child processes and compares.
+Usage (GPU box, after `make -C hier-slam_amd/csrc ablate`):  python tools/check_culling.py [N]"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def child(n):
+    sys.path[:0] = [os.path.join(ROOT, "hier-slam_amd"), os.path.join(ROOT, "tests")]
+    import numpy as np
+    import torch
+    import scenes
+    from harness import run_gpu
+    g = np.random.default_rng(7)
+    out = []
+    for i in range(n):
+        W, H = int(g.integers(17, 260)), int(g.integers(17, 200))
+        P = int(g.choice([50, 400, 1500, 4000]))
+        K = int(g.choice([0, 5, 26]))
+        kind = str(g.choice(["slam", "aniso"]))
+        sm = float(g.choice([0.2, 1.0, 3.0, 10.0, 40.0]))
+        cam, sc, up = scenes.build(W, H, P, K, seed=1000 + i, kind=kind, scale_mult=sm)
+        if i % 3 == 0:   # opacities at and around the alpha >= 1/255 threshold
+            sc["opacities"] = torch.tensor(g.uniform(0.002, 0.02, (P, 1)).astype(np.float32))
+        o, gr, st = run_gpu(cam, sc, up, semantic=True)
+        h = hashlib.sha256()
+        for k in ("color", "semantic", "depth", "median_depth", "opacity"):
+            h.update(np.ascontiguousarray(o[k]).tobytes())
+        h.update(np.ascontiguousarray(st["n_contrib"]).tobytes()); h.update(np.ascontiguousarray(st["final_T"]).tobytes())
+        out.append(dict(case=i, cfg=[W, H, P, K, kind, sm], fwd=h.hexdigest(),
+                        grads={k: [float(np.abs(v).max()), float(np.abs(v).astype(np.float64).sum())] for k, v in gr.items() if v.size}))
+    print("RESULT " + json.dumps(out))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    lib = os.path.join(ROOT, "hier-slam_amd", "libhsr_rast_ablate.so")
+    assert os.path.exists(lib), "build the ablate library first: make -C hier-slam_amd/csrc ablate"
+    res = {}
+    for flags in ("0", "16"):
+        env = dict(os.environ, HSR_RAST_LIB=lib, HSR_GLUE="ctypes", HSR_DEBUG_FLAGS=flags)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=env, capture_output=True, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and line, r.stderr[-3000:]
+        res[flags] = json.loads(line[0][7:])
+    bad_fwd, worst = [], 0.0
+    for a, b in zip(res["0"], res["16"]):
+        if a["fwd"] != b["fwd"]:
+            bad_fwd.append(a["case"])
+        for k in a["grads"]:
+            (ma, sa), (mb, sb) = a["grads"][k], b["grads"][k]
+            worst = max(worst, abs(sa - sb) / max(sa, 1e-30))
+    print(json.dumps(dict(scenes=n, forward_bit_identical=n - len(bad_fwd), forward_differs=bad_fwd,
+                          worst_relative_difference_of_sum_abs_gradient=worst)))
+    return 1 if bad_fwd else 0
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--child":
+        child(int(sys.argv[2]))
+    else:
+        sys.exit(main())
