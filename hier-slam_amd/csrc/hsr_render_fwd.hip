@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
 #pragma unroll
                 for (int c = 0; c < NPF; c++) pf_sink += pf_t[c];
                 const float* grow = a.semantics + (size_t)id_cur * (size_t)a.K + c0;
+                // an entry no sub-block will visit (a fifth to a third of a tile's list: the reference's 3-sigma rectangle lists
+                // splats whose alpha never reaches 1/255 on this tile) needs no row
+                if (qmask != 0u)
 #pragma unroll
                 for (int g0 = 0; g0 < RW; g0 += 32) {
                     float rv[32];

@@ -143,9 +143,9 @@ __device__ __forceinline__ TileGeom tile_geom_sub(int tile, int W, int H, int t)
 //
 // alpha >= 1/255  <=>  Q(d) = A dx^2 + 2 B dx dy + C dy^2 <= 2 ln(255 o) =: tau  (d = splat centre - pixel centre, conic (A, B, C):
 // power = -Q/2, reference forward.cu:481-496): the ellipse E.  A bounding box of E, which is what round 1 tested, keeps every
-// sub-block the box overlaps; for the ~4 px splats of a SLAM map a quarter of those are corners E never reaches, for elongated
-// splats a third (CPU count on the headline scenes: 4.27 M -> 3.18 M sub-block entries and 1.14 M -> 0.86 M forward wave
-// iterations; anisotropic scene 9.15 M -> 6.35 M and 2.38 M -> 1.67 M).  Exact test, one ROW of sub-blocks at a time: the slab
+// sub-block the box overlaps; for the ~4 px splats of a SLAM map an eighth of those are corners E never reaches, for elongated
+// splats a quarter (tests/sim_sublists.py, this function re-evaluated in numpy for every instance of the headline scenes: 3.67 M ->
+// 3.22 M sub-block entries; anisotropic scene 8.38 M -> 6.45 M).  Exact test, one ROW of sub-blocks at a time: the slab
 // dy in [lo, hi] (the row's pixel centres) cuts E in a convex set whose projection on x is an interval [xmin, xmax]; a
 // sub-block of the row is touched iff its dx interval meets it.  For a fixed dy the ellipse spans
 //     dx in (-B dy -+ sqrt(A tau - det dy^2)) / A,
