@@ -211,8 +211,20 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
             const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
-            const float* src = u7 + row * 32 + vi;
-            const float val = (src[0] + src[8]) + (src[16] + src[24]);
+            // raw moments of the row (sums over the four groups' slots) -> the reference's sums (backward.cu:648-660, :887-893):
+            //   dL_dmean2D.x = kx (2 A' Sx + B' Sy), .y = ky (2 C' Sy + B' Sx)   (A', B', C': the pre-scaled conic of the staged record)
+            //   dL_dconic.{x,y,w} = -0.5 {Sxx, Sxy, Syy};  columns 5, 6 (opacity, median depth) pass through
+            const int ja = s_cj[wv][row];
+            const float4 gj = s_geo[ja];
+            const float cxj = s_co[ja].x;
+            const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
+            const float* sa = u7 + row * 32 + ca;
+            const float* sb = u7 + row * 32 + cb;
+            const float ta = (sa[0] + sa[8]) + (sa[16] + sa[24]);
+            const float tb = (sb[0] + sb[8]) + (sb[16] + sb[24]);
+            const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
+            const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
+            const float val = fmaf(wb, tb, wa * ta);
             const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride + (uint32_t)vi;
             if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
@@ -330,13 +342,16 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 const float Gs = active ? G : 0.f;
                 const float gda = Gs * dL_dalpha;
                 const float q = co.y * gda;
+                // The five geometry sums are linear in the RAW moments of q over the pixels — sum q dx, q dy, q dx^2, q dx dy, q dy^2 —
+                // with coefficients that only depend on the splat (conic, 0.5 W, 0.5 H): the lanes reduce the raw moments (5
+                // multiplies instead of 14 instructions per iteration) and the coefficients are applied once per (chunk row, value)
+                // when the row is emitted (flush).
                 float v[SB_NV];
-                v[0] = q * fmaf(2.0f * g.z, dx, g.w * dy) * kx;
-                v[1] = q * fmaf(2.0f * co.x, dy, g.w * dx) * ky;
-                const float hq = -0.5f * q;
-                v[2] = hq * dxx;
-                v[3] = hq * dxy;
-                v[4] = hq * dyy;
+                v[0] = q * dx;
+                v[1] = q * dy;
+                v[2] = q * dxx;
+                v[3] = q * dxy;
+                v[4] = q * dyy;
                 v[5] = gda;
                 v[6] = (active && pos == median_at) ? dpm : 0.f;
                 if (active) {
@@ -448,8 +463,17 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
             const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
-            const float* src = u7 + row * 32 + vi;
-            const float val = (src[0] + src[8]) + (src[16] + src[24]);
+            const int ja = s_cj[wv][row];
+            const float4 gj = s_geo[ja];
+            const float cxj = s_co[ja].x;
+            const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
+            const float* sa = u7 + row * 32 + ca;
+            const float* sb = u7 + row * 32 + cb;
+            const float ta = (sa[0] + sa[8]) + (sa[16] + sa[24]);
+            const float tb = (sb[0] + sb[8]) + (sb[16] + sb[24]);
+            const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
+            const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
+            const float val = fmaf(wb, tb, wa * ta);
             const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride + (uint32_t)vi;
             if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
@@ -555,13 +579,12 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                 const float Gs = active ? G : 0.f;
                 const float gda = Gs * dL_dalpha;
                 const float q = co.y * gda;
-                float v[SB_NV];
-                v[0] = q * fmaf(2.0f * g.z, dx, g.w * dy) * kx;
-                v[1] = q * fmaf(2.0f * co.x, dy, g.w * dx) * ky;
-                const float hq = -0.5f * q;
-                v[2] = hq * dxx;
-                v[3] = hq * dxy;
-                v[4] = hq * dyy;
+                float v[SB_NV];   // raw moments of q; the splat's coefficients are applied at emission (see render_bwd_sub_kernel)
+                v[0] = q * dx;
+                v[1] = q * dy;
+                v[2] = q * dxx;
+                v[3] = q * dxy;
+                v[4] = q * dyy;
                 v[5] = gda;
                 v[6] = fmaf(w, dpd, (active && pos == median_at) ? dpm : 0.f);   // depth: direct sum + median term
                 if (active) {
@@ -715,8 +738,17 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
 #pragma unroll
         for (int pass = 0; pass < (BASE ? 2 : 0); pass++) {
             const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
-            const float* src = u7 + row * 32 + vi;
-            const float val = (src[0] + src[8]) + (src[16] + src[24]);
+            const int ja = s_cj[wv][row];
+            const float4 gj = s_geo[ja];
+            const float cxj = s_co[ja].x;
+            const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
+            const float* sa = u7 + row * 32 + ca;
+            const float* sb = u7 + row * 32 + cb;
+            const float ta = (sa[0] + sa[8]) + (sa[16] + sa[24]);
+            const float tb = (sb[0] + sb[8]) + (sb[16] + sb[24]);
+            const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
+            const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
+            const float val = fmaf(wb, tb, wa * ta);
             const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride + (uint32_t)vi;
             if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
@@ -827,13 +859,12 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
                 const float Gs = active ? G : 0.f;
                 const float gda = Gs * dL_dalpha;
                 const float q = co.y * gda;
-                float v[SB_NV];
-                v[0] = q * fmaf(2.0f * g.z, dx, g.w * dy) * kx;
-                v[1] = q * fmaf(2.0f * co.x, dy, g.w * dx) * ky;
-                const float hq = -0.5f * q;
-                v[2] = hq * dxx;
-                v[3] = hq * dxy;
-                v[4] = hq * dyy;
+                float v[SB_NV];   // raw moments of q; the splat's coefficients are applied at emission (see render_bwd_sub_kernel)
+                v[0] = q * dx;
+                v[1] = q * dy;
+                v[2] = q * dxx;
+                v[3] = q * dxy;
+                v[4] = q * dyy;
                 v[5] = gda;
                 v[6] = (active && pos == median_at) ? dpm : 0.f;
                 if (active) {
