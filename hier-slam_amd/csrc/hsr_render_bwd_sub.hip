@@ -46,6 +46,13 @@ extern "C" int hsr_debug_read_trace_sub(unsigned long long* host, int n)
 
 namespace {
 
+// Makes the staging registers of the next batch "used" BEFORE the first atomics of this batch are issued: hipcc then waits for their
+// loads here — they were issued a chunk of blending ago and have landed — instead of at the next batch's staging, where the same
+// s_waitcnt would also have to sit out every atomic issued in between (loads, stores and atomics retire through one in-order counter).
+#define HSR_SETTLE_STAGING()                                                                                                   \
+    asm volatile("" ::"v"(id_next), "v"(p_xy.x), "v"(p_xy.y), "v"(p_co.x), "v"(p_co.y), "v"(p_co.z), "v"(p_co.w), "v"(p_r), "v"(p_g), \
+                 "v"(p_b), "v"(p_d))
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SB_SLOTS = 16;        // quadrant-list entries per chunk (M dimension of the matrix-core flush)
@@ -235,33 +242,26 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     float2 p_xy = {0, 0};
     float4 p_co = {0, 0, 0, 0};
     float p_r = 0, p_g = 0, p_b = 0, p_d = 0;
-    auto load_id = [&](int hi) {
-        if (t < BATCH && hi - 1 - t >= 0) id_next = (int)a.point_list[range.x + hi - 1 - t];
+    // unconditional, clamped staging loads, the id of the batch after next requested before the next batch's records: see
+    // render_fwd_kernel (a load inside a divergent `if`, or into a register the loads before it took their addresses from, is waited
+    // for where it is issued — and the (rec == NULL) fallback kept three of these values in a scratch slot).  a.rec is never NULL.
+    const int n_list = (int)(range.y - range.x);
+    auto fetch_id = [&](int hi) -> int { return (int)a.point_list[range.x + min(max(hi - 1 - t, 0), max(n_list - 1, 0))]; };
+    auto load_record = [&](int id_of) {
+        const size_t id = (size_t)id_of;
+        id_cur = id_of;
+        const float4* rec = a.rec + 4 * id;
+        const float4 r0 = rec[0], r2 = rec[2];
+        p_co = rec[1];
+        p_xy = make_float2(r0.x, r0.y);
+        p_d = r0.z;
+        p_r = r2.x; p_g = r2.y; p_b = r2.z;
     };
-    auto load_record = [&](int hi) {
-        if (t < BATCH && hi - 1 - t >= 0) {
-            const size_t id = (size_t)id_next;
-            id_cur = id_next;
-            if (a.rec) {
-                const float4* rec = a.rec + 4 * id;
-                const float4 r0 = rec[0], r2 = rec[2];
-                p_co = rec[1];
-                p_xy = make_float2(r0.x, r0.y);
-                p_d = r0.z;
-                p_r = r2.x; p_g = r2.y; p_b = r2.z;
-            } else {
-                p_xy = a.means2D[id];
-                p_co = a.conic_opacity[id];
-                p_r = a.colors[3 * id];
-                p_g = a.colors[3 * id + 1];
-                p_b = a.colors[3 * id + 2];
-                p_d = a.depths[id];
-            }
-        }
-    };
-    load_id(hi_all);
-    load_record(hi_all);
-    load_id(hi_all - BATCH);
+    if (n_list > 0) {
+        const int id0 = fetch_id(hi_all);
+        id_next = fetch_id(hi_all - BATCH);
+        load_record(id0);
+    }
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
@@ -281,14 +281,21 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
-        load_record(hi - BATCH);
-        load_id(hi - 2 * BATCH);
+        {
+            const int id_use = id_next;            // ids of the next batch, requested a whole batch ago
+            id_next = fetch_id(hi - 2 * BATCH);
+            load_record(id_use);
+        }
         TR_ADD(tr_stage, ts);
-        if (hi - cnt >= wmax) continue;   // this wave's pixels all stopped in front of this batch
+        if (hi - cnt >= wmax) {   // this wave's pixels all stopped in front of this batch
+            HSR_SETTLE_STAGING();
+            continue;
+        }
         const long long tl = TR_NOW();
         (void)tl;
 
         const int total = build_flat_list(wv, lane, s_list, s_lcnt, s_flat);
+        if (total == 0) HSR_SETTLE_STAGING();
         for (int c0 = 0; c0 < total; c0 += SB_SLOTS) {
             const int nrows = min(SB_SLOTS, total - c0);
             // lane (group gq, row l16): does chunk entry l16 touch sub-block (wv, gq)?
@@ -366,7 +373,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
             {
                 const long long tf = TR_NOW();
                 (void)tf;
-                flush(nrows);
+                if (c0 == 0) HSR_SETTLE_STAGING();
+            flush(nrows);
                 TR_ADD(tr_flush, tf);
 #ifdef HSR_TRACE
                 tr_chunks++;
@@ -484,33 +492,26 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
     float2 p_xy = {0, 0};
     float4 p_co = {0, 0, 0, 0};
     float p_r = 0, p_g = 0, p_b = 0, p_d = 0;
-    auto load_id = [&](int hi) {
-        if (t < BATCH && hi - 1 - t >= 0) id_next = (int)a.point_list[range.x + hi - 1 - t];
+    // unconditional, clamped staging loads, the id of the batch after next requested before the next batch's records: see
+    // render_fwd_kernel (a load inside a divergent `if`, or into a register the loads before it took their addresses from, is waited
+    // for where it is issued — and the (rec == NULL) fallback kept three of these values in a scratch slot).  a.rec is never NULL.
+    const int n_list = (int)(range.y - range.x);
+    auto fetch_id = [&](int hi) -> int { return (int)a.point_list[range.x + min(max(hi - 1 - t, 0), max(n_list - 1, 0))]; };
+    auto load_record = [&](int id_of) {
+        const size_t id = (size_t)id_of;
+        id_cur = id_of;
+        const float4* rec = a.rec + 4 * id;
+        const float4 r0 = rec[0], r2 = rec[2];
+        p_co = rec[1];
+        p_xy = make_float2(r0.x, r0.y);
+        p_d = r0.z;
+        p_r = r2.x; p_g = r2.y; p_b = r2.z;
     };
-    auto load_record = [&](int hi) {
-        if (t < BATCH && hi - 1 - t >= 0) {
-            const size_t id = (size_t)id_next;
-            id_cur = id_next;
-            if (a.rec) {
-                const float4* rec = a.rec + 4 * id;
-                const float4 r0 = rec[0], r2 = rec[2];
-                p_co = rec[1];
-                p_xy = make_float2(r0.x, r0.y);
-                p_d = r0.z;
-                p_r = r2.x; p_g = r2.y; p_b = r2.z;
-            } else {
-                p_xy = a.means2D[id];
-                p_co = a.conic_opacity[id];
-                p_r = a.colors[3 * id];
-                p_g = a.colors[3 * id + 1];
-                p_b = a.colors[3 * id + 2];
-                p_d = a.depths[id];
-            }
-        }
-    };
-    load_id(hi_all);
-    load_record(hi_all);
-    load_id(hi_all - BATCH);
+    if (n_list > 0) {
+        const int id0 = fetch_id(hi_all);
+        id_next = fetch_id(hi_all - BATCH);
+        load_record(id0);
+    }
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
@@ -528,11 +529,18 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
-        load_record(hi - BATCH);
-        load_id(hi - 2 * BATCH);
-        if (hi - cnt >= wmax) continue;   // this wave's pixels all stopped in front of this batch
+        {
+            const int id_use = id_next;            // ids of the next batch, requested a whole batch ago
+            id_next = fetch_id(hi - 2 * BATCH);
+            load_record(id_use);
+        }
+        if (hi - cnt >= wmax) {   // this wave's pixels all stopped in front of this batch
+            HSR_SETTLE_STAGING();
+            continue;
+        }
 
         const int total = build_flat_list(wv, lane, s_list, s_lcnt, s_flat);
+        if (total == 0) HSR_SETTLE_STAGING();
         for (int c0 = 0; c0 < total; c0 += SB_SLOTS) {
             const int nrows = min(SB_SLOTS, total - c0);
             // lane (group gq, row l16): does chunk entry l16 touch sub-block (wv, gq)?
@@ -596,6 +604,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                 const float total7 = row_reduce_transpose7(v, lane);
                 if (myv_on && valid) u7[r * 32 + gq * 8 + myv] = total7;
             }
+            if (c0 == 0) HSR_SETTLE_STAGING();
             flush(nrows);
         }
     }
@@ -759,33 +768,26 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
     float2 p_xy = {0, 0};
     float4 p_co = {0, 0, 0, 0};
     float p_r = 0, p_g = 0, p_b = 0, p_d = 0;
-    auto load_id = [&](int hi) {
-        if (t < BATCH && hi - 1 - t >= 0) id_next = (int)a.point_list[range.x + hi - 1 - t];
+    // unconditional, clamped staging loads, the id of the batch after next requested before the next batch's records: see
+    // render_fwd_kernel (a load inside a divergent `if`, or into a register the loads before it took their addresses from, is waited
+    // for where it is issued — and the (rec == NULL) fallback kept three of these values in a scratch slot).  a.rec is never NULL.
+    const int n_list = (int)(range.y - range.x);
+    auto fetch_id = [&](int hi) -> int { return (int)a.point_list[range.x + min(max(hi - 1 - t, 0), max(n_list - 1, 0))]; };
+    auto load_record = [&](int id_of) {
+        const size_t id = (size_t)id_of;
+        id_cur = id_of;
+        const float4* rec = a.rec + 4 * id;
+        const float4 r0 = rec[0], r2 = rec[2];
+        p_co = rec[1];
+        p_xy = make_float2(r0.x, r0.y);
+        p_d = r0.z;
+        p_r = r2.x; p_g = r2.y; p_b = r2.z;
     };
-    auto load_record = [&](int hi) {
-        if (t < BATCH && hi - 1 - t >= 0) {
-            const size_t id = (size_t)id_next;
-            id_cur = id_next;
-            if (a.rec) {
-                const float4* rec = a.rec + 4 * id;
-                const float4 r0 = rec[0], r2 = rec[2];
-                p_co = rec[1];
-                p_xy = make_float2(r0.x, r0.y);
-                p_d = r0.z;
-                p_r = r2.x; p_g = r2.y; p_b = r2.z;
-            } else {
-                p_xy = a.means2D[id];
-                p_co = a.conic_opacity[id];
-                p_r = a.colors[3 * id];
-                p_g = a.colors[3 * id + 1];
-                p_b = a.colors[3 * id + 2];
-                p_d = a.depths[id];
-            }
-        }
-    };
-    load_id(hi_all);
-    load_record(hi_all);
-    load_id(hi_all - BATCH);
+    if (n_list > 0) {
+        const int id0 = fetch_id(hi_all);
+        id_next = fetch_id(hi_all - BATCH);
+        load_record(id0);
+    }
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
@@ -803,11 +805,18 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
-        load_record(hi - BATCH);
-        load_id(hi - 2 * BATCH);
-        if (hi - cnt >= wmax) continue;   // this wave's pixels all stopped in front of this batch
+        {
+            const int id_use = id_next;            // ids of the next batch, requested a whole batch ago
+            id_next = fetch_id(hi - 2 * BATCH);
+            load_record(id_use);
+        }
+        if (hi - cnt >= wmax) {   // this wave's pixels all stopped in front of this batch
+            HSR_SETTLE_STAGING();
+            continue;
+        }
 
         const int total = build_flat_list(wv, lane, s_list, s_lcnt, s_flat);
+        if (total == 0) HSR_SETTLE_STAGING();
         for (int c0 = 0; c0 < total; c0 += SB_SLOTS) {
             const int nrows = min(SB_SLOTS, total - c0);
             // lane (group gq, row l16): does chunk entry l16 touch sub-block (wv, gq)?
@@ -876,6 +885,7 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
                 const float total7 = row_reduce_transpose7(v, lane);
                 if (myv_on && valid) u7[r * 32 + gq * 8 + myv] = total7;
             }
+            if (c0 == 0) HSR_SETTLE_STAGING();
             flush(nrows);
         }
     }

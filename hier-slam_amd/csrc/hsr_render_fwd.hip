@@ -128,34 +128,24 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
     float pf_sink = 0.f;
     int id_cur = 0;            // id of the splat whose record sits in p_* (PF: its row is fetched when it is staged)
 
-    auto load_id = [&](int start) {
-        const int i = start + t;
-        if (t < BATCH && i < n) id_next = (int)a.point_list[range.x + i];
-    };
-    auto load_record = [&](int start) {
-        const int i = start + t;
-        if (t < BATCH && i < n) {
-            const size_t id = (size_t)id_next;
-            id_cur = id_next;
-            if (a.rec) {
-                const float4* rec = a.rec + 4 * id;
-                const float4 r0 = rec[0];
-                p_co = rec[1];
-                p_xy = make_float2(r0.x, r0.y);
-                p_d = r0.z;
-                if (BASE) {
-                    const float4 r2 = rec[2];
-                    p_r = r2.x; p_g = r2.y; p_b = r2.z;
-                }
-            } else {
-                p_xy = a.means2D[id];
-                p_co = a.conic_opacity[id];
-                p_d = a.depths[id];
-                if (BASE) {
-                    p_r = a.colors[3 * id];
-                    p_g = a.colors[3 * id + 1];
-                    p_b = a.colors[3 * id + 2];
-                }
+    // Staging loads are UNCONDITIONAL (clamped indices; lanes past the end of the list fetch a duplicate they never stage) and the
+    // id of batch b+2 is requested BEFORE the records of batch b+1: a load inside a divergent `if` lands in a temporary that is
+    // copied into the loop-carried register at the end of the branch, and that copy — like a load that overwrites the register the
+    // previous loads took their addresses from — makes hipcc wait for everything in flight right there, i.e. the "pipelined" gathers
+    // were waited for where they were issued (round 1 and most of round 2: s_waitcnt vmcnt(0) 30 instructions after the loads).
+    auto fetch_id = [&](int start) -> int { return (int)a.point_list[range.x + min(max(start + t, 0), n - 1)]; };
+    auto load_record = [&](int id_of) {
+        const size_t id = (size_t)id_of;
+        id_cur = id_of;
+        {
+            const float4* rec = a.rec + 4 * id;
+            const float4 r0 = rec[0];
+            p_co = rec[1];
+            p_xy = make_float2(r0.x, r0.y);
+            p_d = r0.z;
+            if (BASE) {
+                const float4 r2 = rec[2];
+                p_r = r2.x; p_g = r2.y; p_b = r2.z;
             }
             if (KC > 0 && PF) {
                 const float* row = a.semantics + id * (size_t)a.K + c0;
@@ -179,9 +169,12 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
             }
         }
     };
-    load_id(0);
-    load_record(0);
-    load_id(BATCH);
+    if (n > 0) {
+        const int id0 = fetch_id(0);
+        id_next = fetch_id(BATCH);
+        load_record(id0);
+    }
+
 
     for (int start = 0; start < n; start += BATCH) {
         const bool wave_done = __ballot(!done) == 0ull;
@@ -258,8 +251,11 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
         const long long tl0 = TRF_NOW();
         (void)tl0;
         // next batch's gathers go out now and land while this batch is blended
-        load_record(start + BATCH);
-        load_id(start + 2 * BATCH);
+        {
+            const int id_use = id_next;            // ids of batch b+1, requested a whole batch ago
+            id_next = fetch_id(start + 2 * BATCH);
+            load_record(id_use);
+        }
         if (wave_done) continue;
 
         if constexpr (SUB) {
