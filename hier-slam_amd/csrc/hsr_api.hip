@@ -373,7 +373,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
         BinState none{nullptr, nullptr, nullptr, nullptr, nullptr};
         {
             StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
-            hsr_launch_bin_emit(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, nullptr, stream, &ref);
+            hsr_launch_bin_emit(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, nullptr, stream, &ref);
         }
         {
             StageTimer tm(HSR_STAGE_FWD_SORT, stream);
@@ -416,9 +416,9 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     BinState b;
     hsr_carve_bin(bptr, R, &b);
 
-    if (binned && R > 0) {
+    if (binned) {   // also when R == 0: its first workgroup writes the tile ranges
         StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
-        hsr_launch_bin_emit(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, b.keys, stream);
+        hsr_launch_bin_emit(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, b.keys, stream);
     }
     if (binned) {
         HSR_LAUNCH_CHECK(in.debug, stream);

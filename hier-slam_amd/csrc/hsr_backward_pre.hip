@@ -118,11 +118,30 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
     if (KC < 0 && a.grow && a.K > 0 && a.out_semantics) {
         // packed mode: the block unpacks the semantic columns of its 256 rows cooperatively — consecutive
         // lanes read consecutive floats of a row and write one contiguous [256, K] slab of dL_dsemantics
+        // (row, column) of element e advance incrementally — no division in the loop — and four loads are in flight per lane
         const int g0 = blockIdx.x * 256;
         const int ng = min(256, a.P - g0);
-        for (int e = threadIdx.x; e < ng * a.K; e += 256) {
-            const int gi = e / a.K, c = e - gi * a.K;
-            a.out_semantics[(size_t)g0 * a.K + e] = a.grow[(size_t)(g0 + gi) * a.grow_stride + HSR_GROW_SEM0 + c];
+        const int K = a.K, total = ng * K;
+        const int dgi = 256 / K, dc = 256 - dgi * K;          // e += 256: row += dgi, column += dc (then one carry)
+        int gi = (int)threadIdx.x / K, c = (int)threadIdx.x - gi * K;
+        const float* src = a.grow + (size_t)g0 * a.grow_stride + HSR_GROW_SEM0;
+        float* dst = a.out_semantics + (size_t)g0 * K;
+        int e = threadIdx.x;
+        for (; e + 768 < total; e += 1024) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                v[u] = src[(size_t)gi * a.grow_stride + c];
+                gi += dgi; c += dc;
+                if (c >= K) { c -= K; gi++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) dst[e + 256 * u] = v[u];
+        }
+        for (; e < total; e += 256) {
+            dst[e] = src[(size_t)gi * a.grow_stride + c];
+            gi += dgi; c += dc;
+            if (c >= K) { c -= K; gi++; }
         }
     }
     if (idx >= a.P) return;

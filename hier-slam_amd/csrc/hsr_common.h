@@ -141,9 +141,10 @@ struct HsrBinPlan { int nblk, per_block; };   // direct tile binning: workgroups
 bool hsr_bin_plan(int P, int T, size_t scratch_words, HsrBinPlan* plan);   // false = not applicable (radix path)
 int hsr_launch_bin_count(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, uint32_t* scratch,
                          uint2* ranges, hipStream_t stream, uint32_t* host_counter = nullptr, uint32_t host_seq = 0);
-                         // per-tile counts -> ranges; produces num_rendered (counters[0]; also {value, seq} into host-mapped memory)
+                         // per-tile counts; produces num_rendered (counters[0]; also {value, seq} into host-mapped memory)
 int hsr_launch_bin_emit(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, const uint32_t* scratch,
-                        uint64_t* comp, hipStream_t stream, const BinDevRef* ref = nullptr);   // (depth, index) composites into the tile segments
+                        uint2* ranges, uint64_t* comp, hipStream_t stream, const BinDevRef* ref = nullptr);
+                        // tile ranges; (depth, index) composites into the tile segments
 int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStream_t stream, const BinDevRef* ref = nullptr,
                          int avg_per_tile_hint = 0);  // per-tile (depth, index) sort; hint: entries per tile of the previous frame
 int hsr_sort_tile_passes(int end_bit);

@@ -340,14 +340,13 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t*
 //                table[nblk][T]; also finishes the per-Gaussian inclusive scan (point_offsets), which no longer feeds
 //                the emission but is part of the state the reference keeps (rasterizer_impl.cu:281);
 //   bin_scan   : thread = tile: exclusive prefix over the nblk rows in place, tile totals;
-//   bin_offsets: one workgroup: exclusive scan of the tile totals = tile segment starts = the reference's tile ranges
-//                (identifyTileRanges, rasterizer_impl.cu:116-138; untouched tiles keep {0,0} as after its memset, :314);
-//   bin_emit   : same ownership as bin_hist; LDS cursors (segment start + row prefix), ds_add_rtn gives each instance
+//   bin_emit   : same ownership as bin_hist; every workgroup scans the tile totals itself (= tile segment starts = the reference's
+//                tile ranges, written by workgroup 0); LDS cursors (segment start + row prefix), ds_add_rtn gives each instance
 //                its slot (it stores the 8-byte sort composite (depth bits, index) there; the tile is implied by the
 //                segment).  The order INSIDE a tile segment is whatever the LDS atomics produce — irrelevant, because
 //                tile_sort_kernel then orders each segment by the unique composite (depth bits, Gaussian index), which
 //                is exactly the order a stable sort of the emission order on (tile, depth) gives.
-// Bit-identical sorted keys / values / ranges, 4 small launches instead of 8, and the 12 B x R unsorted copy is gone.
+// Bit-identical sorted keys / values / ranges, 3 small launches instead of 8, and the 12 B x R unsorted copy is gone.
 constexpr int BIN_MAX_TILES = 8192;   // LDS: one u32 counter per tile
 
 constexpr int BIN_THREADS = 1024;     // 16 waves per workgroup: each workgroup touches all T counters twice (zero / read
@@ -455,31 +454,9 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(int T, int nblk, uint32_
         run += c;
     }
 }
-__global__ void __launch_bounds__(1024) bin_offsets_kernel(int T, const uint32_t* __restrict__ totals, uint32_t* __restrict__ base,
-                                                           uint2* __restrict__ ranges)
-{
-    __shared__ uint32_t smem[1024 / 64 + 1];
-    const int per = (T + 1023) / 1024;
-    const int beg = threadIdx.x * per;
-    uint32_t local = 0;
-    for (int i = 0; i < per; i++)
-        if (beg + i < T) local += totals[beg + i];
-    uint32_t total;
-    uint32_t run = block_exclusive_scan<1024>(local, smem, total);
-    for (int i = 0; i < per; i++) {
-        const int j = beg + i;
-        if (j < T) {
-            const uint32_t c = totals[j];
-            base[j] = run;
-            ranges[j] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);
-            run += c;
-        }
-    }
-}
-
 __global__ void __launch_bounds__(BIN_THREADS) bin_emit_kernel(int P, int per_block, const int* __restrict__ radii, int tiles_x, int tiles_y,
-                                                       GeomState g, const uint32_t* __restrict__ table, const uint32_t* __restrict__ base,
-                                                       uint64_t* __restrict__ comp, BinDevRef ref)
+                                                       GeomState g, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
+                                                       uint2* __restrict__ ranges, uint64_t* __restrict__ comp, BinDevRef ref)
 {
     if (ref.base) {   // speculative forward: the array lives where num_rendered says
         BinState bs;
@@ -487,9 +464,34 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_emit_kernel(int P, int per_bl
         comp = bs.keys;
     }
     extern __shared__ uint32_t s_cur[];   // [T]
+    __shared__ uint32_t s_scan[BIN_THREADS / 64 + 1];
     const int T = tiles_x * tiles_y;
     const uint32_t* row = table + (size_t)blockIdx.x * T;
-    for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cur[i] = base[i] + row[i];
+    // segment starts = exclusive scan of the tile totals: every workgroup scans the (L2-resident) totals itself — T <= 8192 words,
+    // at most 8 per thread — instead of reading them from a single-workgroup launch of their own; workgroup 0 also writes the
+    // reference's tile ranges (identifyTileRanges, rasterizer_impl.cu:116-138; untouched tiles keep {0,0} as after its memset, :314)
+    {
+        const int per = (T + BIN_THREADS - 1) / BIN_THREADS;
+        const int beg = threadIdx.x * per;
+        uint32_t cnt[BIN_MAX_TILES / BIN_THREADS];
+        uint32_t local = 0;
+#pragma unroll
+        for (int i = 0; i < BIN_MAX_TILES / BIN_THREADS; i++) {
+            cnt[i] = (i < per && beg + i < T) ? totals[beg + i] : 0u;
+            local += cnt[i];
+        }
+        uint32_t total;
+        uint32_t run = block_exclusive_scan<BIN_THREADS>(local, s_scan, total);
+#pragma unroll
+        for (int i = 0; i < BIN_MAX_TILES / BIN_THREADS; i++) {
+            const int j = beg + i;
+            if (i < per && j < T) {
+                s_cur[j] = run + row[j];
+                if (blockIdx.x == 0) ranges[j] = cnt[i] ? make_uint2(run, run + cnt[i]) : make_uint2(0u, 0u);
+                run += cnt[i];
+            }
+        }
+    }
     __syncthreads();
     const int g0 = blockIdx.x * per_block;
     const int g1 = min(P, g0 + per_block);
@@ -562,22 +564,22 @@ int hsr_launch_bin_count(const HsrBinPlan& plan, int P, const int* radii, int ti
     const int T = tiles_x * tiles_y;
     uint32_t* table = scratch;
     uint32_t* totals = table + (size_t)plan.nblk * T;
-    uint32_t* base = totals + T;
+    (void)ranges;   // written by bin_emit_kernel's workgroup 0, from the same totals
     bin_hist_kernel<<<plan.nblk, BIN_THREADS, (size_t)T * sizeof(uint32_t), stream>>>(P, plan.per_block, radii, tiles_x, tiles_y, g, table,
                                                                                      host_counter, host_seq);
     bin_scan_kernel<<<(T + BIN_SCAN_TILES - 1) / BIN_SCAN_TILES, 1024, 0, stream>>>(T, plan.nblk, table, totals);
-    bin_offsets_kernel<<<1, 1024, 0, stream>>>(T, totals, base, ranges);
     return HSR_OK;
 }
 
 int hsr_launch_bin_emit(const HsrBinPlan& plan, int P, const int* radii, int tiles_x, int tiles_y, GeomState& g, const uint32_t* scratch,
-                        uint64_t* comp, hipStream_t stream, const BinDevRef* ref)
+                        uint2* ranges, uint64_t* comp, hipStream_t stream, const BinDevRef* ref)
 {
     const int T = tiles_x * tiles_y;
     const uint32_t* table = scratch;
-    const uint32_t* base = table + (size_t)plan.nblk * T + T;
+    const uint32_t* totals = table + (size_t)plan.nblk * T;
     bin_emit_kernel<<<plan.nblk, BIN_THREADS, (size_t)T * sizeof(uint32_t), stream>>>(P, plan.per_block, radii, tiles_x, tiles_y, g, table,
-                                                                                      base, comp, ref ? *ref : BinDevRef{nullptr, nullptr, 0});
+                                                                                      totals, ranges, comp,
+                                                                                      ref ? *ref : BinDevRef{nullptr, nullptr, 0});
     return HSR_OK;
 }
 

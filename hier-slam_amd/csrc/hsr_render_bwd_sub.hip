@@ -75,6 +75,35 @@ __device__ __forceinline__ float row_reduce_transpose7(const float (&v)[7], int 
     return pair_dpp<DPP_QUAD_XOR2>(c, 0.f, b1);
 }
 
+// ---- fp32 products on the bf16 matrix cores: the exact three-way split ----
+// v_mfma_f32_16x16x4_f32 is the slow matrix instruction of gfx950 (32 cycles for 1024 multiply-adds, measured: tools/micro/valu_rate.hip);
+// v_mfma_f32_16x16x32_bf16 does 8192 in 16.  An fp32 number is EXACTLY hi + mid + lo with three bf16 numbers of 8 significant bits
+// each (truncate, subtract, truncate, subtract: the 24-bit significand is cut in three), so a * b = sum of nine bf16 products, each exact
+// in the fp32 accumulator; the six kept here (all but mid*lo, lo*mid, lo*lo) leave a relative error <= 2^-23 per product — the size of
+// one fp32 rounding.  Six 16-cycle instructions over 32 pixels replace eight 32-cycle ones over 4 pixels each.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const uint32_t a0 = __float_as_uint(x[e]), a1 = __float_as_uint(x[e + 1]);
+        const float r0 = x[e] - __uint_as_float(a0 & 0xFFFF0000u), r1 = x[e + 1] - __uint_as_float(a1 & 0xFFFF0000u);
+        const uint32_t b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+        const float t0 = r0 - __uint_as_float(b0 & 0xFFFF0000u), t1 = r1 - __uint_as_float(b1 & 0xFFFF0000u);
+        // the upper halves of two registers, packed (element e in the low half)
+        hi[e / 2] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+        mid[e / 2] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        lo[e / 2] = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+    }
+}
+
+__device__ __forceinline__ f32x4 mma_bf16(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 template <int KC, int BATCH>
 __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
 {
@@ -613,10 +642,14 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
 // Wide trees (K > 27), in channel passes like hsr_render_bwd_wide.hip: semantic channels [c0, c0 + ns) of the image; the BASE
 // pass adds the five direct sums and the seven butterfly values, a SEM pass only re-derives alpha and T and feeds the panel.
 // 16 * NG >= ns + (BASE ? 5 : 0).
-template <int NG, bool BASE, int BATCH>
-__global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_bwd_subw_kernel(RenderBwdArgs a, int c0, int ns)
+// BF: the panel contraction runs on the bf16 matrix cores (split3_bf16): 24 registers of B operand per 16 columns instead of 16.
+template <int NG, bool BASE, int BATCH, bool BF>
+__global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2))) render_bwd_subw_kernel(RenderBwdArgs a, int c0, int ns)
 {
     static_assert(NG <= 7, "at most 112 channels per pass (the B operand lives in 16 * NG registers)");
+    static_assert(!BF || NG <= 5, "the split B operand of more than 80 columns does not fit the register file at two waves per SIMD");
+    constexpr int STRIDE = BF ? 68 : SB_STRIDE;   // floats per panel row; 68: rows 16-byte aligned, b128 reads of 16 rows hit 64 banks
+    static_assert(SB_SLOTS * STRIDE <= SB_PANEL, "panel");
     static_assert(BATCH <= 256, "batch slots are bytes");
     __shared__ float4 s_geo[BATCH];
     __shared__ float2 s_co[BATCH];
@@ -667,7 +700,8 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
     if (lane == 0) s_wmax[wv] = wmax;
 
     // ---- the MFMA B operand: G transposed through LDS (lane l holds G[pixel lane 4m + (l>>4)][channel 16g + (l&15)]) ----
-    float Breg[NG][16];
+    float Breg[BF ? 1 : NG][16];
+    u32x4 Bh[BF ? NG : 1][2], Bm[BF ? NG : 1][2], Bl[BF ? NG : 1][2];   // BF: pixels 32 s + 8 (l>>4) + e, e = 0..7, of channel 16 g + (l&15)
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         float gv[16];
@@ -688,8 +722,18 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
 #pragma unroll
         for (int c = 0; c < 16; c++) panel[lane * 17 + c] = gv[c];
         __syncthreads();
+        if (BF) {
 #pragma unroll
-        for (int m = 0; m < 16; m++) Breg[g][m] = panel[(4 * m + (lane >> 4)) * 17 + (lane & 15)];
+            for (int s2 = 0; s2 < 2; s2++) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) x[e] = panel[(32 * s2 + 8 * (lane >> 4) + e) * 17 + (lane & 15)];
+                split3_bf16(x, Bh[g][s2], Bm[g][s2], Bl[g][s2]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; m++) Breg[g][m] = panel[(4 * m + (lane >> 4)) * 17 + (lane & 15)];
+        }
         __syncthreads();
     }
     const int hi_all = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
@@ -713,8 +757,8 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
     auto clear_chunk = [&]() {
         float2* p2 = reinterpret_cast<float2*>(panel);
 #pragma unroll
-        for (int i = 0; i < (SB_SLOTS * SB_STRIDE) / 2; i += 64)
-            if (i + lane < (SB_SLOTS * SB_STRIDE) / 2) p2[i + lane] = make_float2(0.f, 0.f);
+        for (int i = 0; i < (SB_SLOTS * STRIDE) / 2; i += 64)
+            if (i + lane < (SB_SLOTS * STRIDE) / 2) p2[i + lane] = make_float2(0.f, 0.f);
         if (BASE) {
             float4* u4 = reinterpret_cast<float4*>(u7);
 #pragma unroll
@@ -726,12 +770,37 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
         f32x4 acc[NG];
 #pragma unroll
         for (int g = 0; g < NG; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* arow = panel + l16 * SB_STRIDE + (lane >> 4);
+        if (BF) {
 #pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const float av = arow[4 * m];
+            for (int s2 = 0; s2 < 2; s2++) {
+                // row l16, pixels 32 s + 8 (l>>4) .. + 7: two aligned b128 reads
+                const float4* ap = reinterpret_cast<const float4*>(panel + l16 * STRIDE + 32 * s2 + 8 * (lane >> 4));
+                const float4 x0 = ap[0], x1 = ap[1];
+                const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                u32x4 Ah, Am, Al;
+                split3_bf16(x, Ah, Am, Al);
+                // small products first
 #pragma unroll
-            for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Breg[g][m], acc[g], 0, 0, 0);
+                for (int g = 0; g < NG; g++) acc[g] = mma_bf16(Al, Bh[g][s2], acc[g]);
+#pragma unroll
+                for (int g = 0; g < NG; g++) acc[g] = mma_bf16(Ah, Bl[g][s2], acc[g]);
+#pragma unroll
+                for (int g = 0; g < NG; g++) acc[g] = mma_bf16(Am, Bm[g][s2], acc[g]);
+#pragma unroll
+                for (int g = 0; g < NG; g++) acc[g] = mma_bf16(Am, Bh[g][s2], acc[g]);
+#pragma unroll
+                for (int g = 0; g < NG; g++) acc[g] = mma_bf16(Ah, Bm[g][s2], acc[g]);
+#pragma unroll
+                for (int g = 0; g < NG; g++) acc[g] = mma_bf16(Ah, Bh[g][s2], acc[g]);
+            }
+        } else {
+            const float* arow = panel + l16 * STRIDE + (lane >> 4);
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const float av = arow[4 * m];
+#pragma unroll
+                for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Breg[g][m], acc[g], 0, 0, 0);
+            }
         }
         // D[row = 4*(lane>>4) + r][col = lane&15]: one atomic wave-instruction per register = 4 rows x 64 bytes
 #pragma unroll
@@ -855,7 +924,7 @@ __global__ void __launch_bounds__(256, NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)) render_b
                 const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
                 const float test_T = T * inv_one_m_a;
                 const float w = active ? alpha * test_T : 0.f;
-                if (valid) panel[r * SB_STRIDE + lane] = w;
+                if (valid) panel[r * STRIDE + lane] = w;
 
                 if (!BASE) {
                     if (active) T = test_T;
@@ -913,13 +982,20 @@ void launch_subw_pass(const RenderBwdArgs& a, int c0, int ns, dim3 grid, hipStre
 {
     const int groups = (ns + (BASE ? 5 : 0) + 15) / 16;
     const dim3 block(256);
-    if (groups <= 1) render_bwd_subw_kernel<1, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
-    else if (groups == 2) render_bwd_subw_kernel<2, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
-    else if (groups == 3) render_bwd_subw_kernel<3, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
-    else if (groups == 4) render_bwd_subw_kernel<4, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
-    else if (groups == 5) render_bwd_subw_kernel<5, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
-    else if (groups == 6) render_bwd_subw_kernel<6, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
-    else render_bwd_subw_kernel<7, BASE, 224><<<grid, block, 0, stream>>>(a, c0, ns);
+    // bf16 matrix cores on the exact three-way split where they paid (tools/wide_mma_ab.sh, 500k Gaussians, bwd_render ms, fp32 -> split):
+    // 4 column groups 0.495 -> 0.486, 5 groups 0.606 -> 0.573 (1920x1080, 2M: 2.168 -> 2.058); 3 groups lose (0.407 -> 0.419: 24 B
+    // registers per group push the kernel from 3 waves per SIMD to 2); 2 groups (K <= 27) tie even at 3 waves; 6 and 7 groups do not fit.
+    static const char* e_mma = getenv("HSR_BWD_WIDE_MMA");   // kernel-family selector (parity-tested): "f32" = fp32 matrix instructions
+    const bool bf = !(e_mma && !strcmp(e_mma, "f32"));
+    if (groups <= 1) render_bwd_subw_kernel<1, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 2) render_bwd_subw_kernel<2, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 3) render_bwd_subw_kernel<3, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 4 && bf) render_bwd_subw_kernel<4, BASE, 224, true><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 4) render_bwd_subw_kernel<4, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 5 && bf) render_bwd_subw_kernel<5, BASE, 224, true><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 5) render_bwd_subw_kernel<5, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
+    else if (groups == 6) render_bwd_subw_kernel<6, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
+    else render_bwd_subw_kernel<7, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
 }
 }  // namespace
 

@@ -185,15 +185,17 @@ def test_parity_alternate_kernels(impl):
 
 def test_parity_wide_tree_kernel_selectors():
     """wide trees (K > 27) default to ONE backward pass of up to 112 columns at two waves per SIMD; HSR_BWD_WIDE_PASS=split
-    selects the earlier 64-column passes (what K + 5 > 112 still takes): same results, parity cases in a child process"""
+    selects the earlier 64-column passes (what K + 5 > 112 still takes); 49..80 columns contract their panels on the bf16 matrix
+    cores (exact three-way split of the fp32 operands), HSR_BWD_WIDE_MMA=f32 keeps them on the fp32 matrix instructions:
+    same results, parity cases in a child process"""
     import subprocess
     import sys
     code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
             "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
-            "for n in ('generic_k40_two_chunks','large_tree_k74','flat_k102','odd_k33','odd_k75_ragged','k124_widest_single_pass','k130_chunked','wide_deep_tiles_k76')];print('ok')")
+            "for n in ('generic_k40_two_chunks','large_tree_k74','flat_k102','odd_k33','odd_k75_ragged','k52_four_column_groups','k124_widest_single_pass','k130_chunked','wide_deep_tiles_k76')];print('ok')")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # + the K = 74 forward with its rows parked in registers, + the matrix-core forward in its round-1 range (29..124)
-    for extra in (dict(HSR_BWD_WIDE_PASS="split"), dict(HSR_FWD_PF="0"), dict(HSR_FWD_IMPL="wide")):
+    for extra in (dict(HSR_BWD_WIDE_PASS="split"), dict(HSR_BWD_WIDE_MMA="f32"), dict(HSR_FWD_PF="0"), dict(HSR_FWD_IMPL="wide")):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
 

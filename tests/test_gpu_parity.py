@@ -24,6 +24,7 @@ CASES = {
     "flat_k102": (80, 48, 800, 102, "slam", 3.0, True, "sr", (0, 0, 0), 0.0),
     "odd_k33": (96, 64, 1200, 33, "aniso", 2.0, True, "sr", (0, 0, 0), 0.0),     # unaligned rows, 2 channel blocks
     "odd_k75_ragged": (100, 70, 1500, 75, "aniso", 2.5, True, "sr", (0.3, 0.2, 0.1), 0.0),
+    "k52_four_column_groups": (100, 70, 1500, 52, "aniso", 2.5, True, "sr", (0.1, 0.2, 0.3), 0.0),   # bf16-split contraction, 4 groups
     "k124_widest_single_pass": (64, 48, 600, 124, "slam", 3.0, True, "sr", (0, 0, 0), 0.0),
     "k130_chunked": (64, 48, 600, 130, "slam", 3.0, True, "sr", (0, 0, 0), 0.0),
     "wide_deep_tiles_k76": (64, 48, 1500, 76, "aniso", 40.0, True, "sr", (0, 0, 0), 0.0),  # many batches, early termination

@@ -10,10 +10,12 @@
 #include <algorithm>
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 // MODE 0: 16 independent v_fma_f32 per iteration     1: 8 independent v_pk_fma_f32 (16 lanes-worth of fma each... 2 fma/lane)
 // MODE 2: 16 independent v_exp_f32                   3: 4 independent v_mfma_f32_16x16x4_f32
 // MODE 4: 4 MFMA + 16 v_fma interleaved 1:4          5: 4 MFMA + 32 v_fma interleaved 1:8
+// MODE 6: 4 independent v_mfma_f32_16x16x32_bf16     7: 4 bf16 MFMA + 32 v_fma interleaved 1:8   (the 3 x bf16 split of an fp32 product)
 template <int MODE>
 __global__ void k(float* out, unsigned long long* cyc, int iters)
 {
@@ -44,6 +46,18 @@ __global__ void k(float* out, unsigned long long* cyc, int iters)
         } else if (MODE == 3) {
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], a[i + 4], acc[i], 0, 0, 0);
+        } else if (MODE == 6 || MODE == 7) {
+            union { float f[4]; v8bf v; } ua, ub;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { ua.f[i] = a[12 + i]; ub.f[i] = a[12 + ((i + 1) & 3)]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
+                if (MODE == 7) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[(i * 8 + j) % 12]) : "v"(m), "v"(c));
+                }
+            }
         } else {
             constexpr int PER = MODE == 4 ? 4 : 8;
 #pragma unroll
@@ -101,6 +115,8 @@ int main()
         run<3>("v_mfma_f32_16x16x4_f32 x4 independent", w, 0, 4);
         run<4>("mfma16x16x4 + 4 v_fma each", w, 16, 4);
         run<5>("mfma16x16x4 + 8 v_fma each", w, 32, 4);
+        run<6>("v_mfma_f32_16x16x32_bf16 x4 independent", w, 0, 4);
+        run<7>("mfma16x16x32_bf16 + 8 v_fma each", w, 32, 4);
     }
     return 0;
 }
