@@ -44,6 +44,90 @@ extern "C" int hsr_debug_read_trace_fwd(unsigned long long* host, int n)
 
 namespace {
 
+// x of lane Q of the caller's quad (lanes 4i .. 4i+3), as a DPP operand: folds into the consuming v_fmac_f32 (no instruction of its own)
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), Q * 0x55, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float quad_bcast_q(float x, int q)   // q: a constant after unrolling
+{
+    switch (q) {
+    case 0: return quad_bcast<0>(x);
+    case 1: return quad_bcast<1>(x);
+    case 2: return quad_bcast<2>(x);
+    default: return quad_bcast<3>(x);
+    }
+}
+
+// s[4 r + q] += x[r](quad lane q) * w for r < W, q < 4: the value travels in the FMA's own DPP operand.  Written as ONE asm block per
+// group of up to 16 channels because hipcc keeps its packed FMAs and materialises every broadcast with a v_mov_b32_dpp of its own (two
+// instructions per channel instead of one); the leading s_nop covers gfx9's "VALU write -> DPP read" wait states whatever the
+// compiler put in front of the block (inside it nothing writes an x[]).
+template <int W>
+__device__ __forceinline__ void quad_fma_words(float (&s)[16], const float (&x)[4], float w)
+{
+    static_assert(W >= 1 && W <= 4, "1..4 words = 4..16 channels per block");
+    if constexpr (W == 4) {
+        asm("s_nop 1\n\t"
+            "v_fmac_f32_dpp %0, %16, %20 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %16, %20 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %16, %20 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %16, %20 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %4, %17, %20 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %5, %17, %20 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %6, %17, %20 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %7, %17, %20 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %8, %18, %20 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %9, %18, %20 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %10, %18, %20 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %11, %18, %20 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %12, %19, %20 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %13, %19, %20 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %14, %19, %20 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %15, %19, %20 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+            : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]), "+v"(s[8]), "+v"(s[9]), "+v"(s[10]), "+v"(s[11]), "+v"(s[12]), "+v"(s[13]), "+v"(s[14]), "+v"(s[15])
+            : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(w));
+    } else if constexpr (W == 3) {
+        asm("s_nop 1\n\t"
+            "v_fmac_f32_dpp %0, %12, %15 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %12, %15 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %12, %15 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %12, %15 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %4, %13, %15 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %5, %13, %15 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %6, %13, %15 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %7, %13, %15 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %8, %14, %15 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %9, %14, %15 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %10, %14, %15 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %11, %14, %15 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+            : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]), "+v"(s[8]), "+v"(s[9]), "+v"(s[10]), "+v"(s[11])
+            : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(w));
+    } else if constexpr (W == 2) {
+        asm("s_nop 1\n\t"
+            "v_fmac_f32_dpp %0, %8, %10 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %8, %10 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %8, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %8, %10 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %4, %9, %10 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %5, %9, %10 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %6, %9, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %7, %9, %10 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+            : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7])
+            : "v"(x[0]), "v"(x[1]), "v"(w));
+    } else {
+        asm("s_nop 1\n\t"
+            "v_fmac_f32_dpp %0, %4, %5 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %4, %5 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %4, %5 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %4, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+            : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3])
+            : "v"(x[0]), "v"(w));
+    }
+}
+
 template <int KC>
 struct FwdCfg {
     // LDS per staged splat: 32 (x, y, A, B, C, opacity, r, g) + 4 * round4(KC + 2) (features, b, depth)
@@ -71,6 +155,17 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
     // pair up with the packed FMAs (blue and depth ride in the row's padding at K = 26): one LDS read and one address
     // computation fewer per visit than four separate arrays
     constexpr int RW = (KC + 2 + 3) & ~3;
+    // QS (sub-block lists with features): the 16 lanes of a group all visit the SAME splat, so a row read by every lane moves the
+    // same 4 * RW bytes through the LDS crossbar 16 times — and at 128 bytes per cycle and CU that, not the FMAs, is what a feature
+    // channel costs (measured: 2.2-2.8 CU cycles per channel and wave visit against 0.44 for the packed FMAs).  Instead each lane
+    // of a QUAD reads a quarter of the row (full 16-channel groups are stored [quad lane][4]: lane q's b128 holds channels
+    // q, q+4, q+8, q+12 of the group; the last, partial group stays in channel order and is read a word at a time) and the FMAs
+    // take the value from the quad lane that holds it through their DPP operand (quad_perm: no extra instruction, no LDS).
+    // Taken where it pays (tools/sweep.sh, 500k Gaussians): the wide per-lane kernels (PF: K = 74 0.393 -> 0.363 ms, 1920x1080 / 2M
+    // 1.313 -> 1.257 ms); at K = 16 / 26 the 2 K single FMAs against K packed ones cancel the LDS saving (0.144 -> 0.158, 0.175 -> 0.176).
+    constexpr bool QS = SUB && PF && KC > 0;
+    constexpr int NGF = QS ? RW / 16 : 0;            // full 16-channel groups
+    constexpr int REM = QS ? (RW % 16) / 4 : 0;      // words per lane of the partial group
     __shared__ float4 s_rec[BATCH * 2];
     __shared__ float4 s_row[BATCH * (RW / 4)];
     __shared__ uint8_t s_list[SUB ? 1 : 4][256];
@@ -227,7 +322,14 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
                     }
 #pragma unroll
                     for (int q = 0; q < 8; q++)
-                        if (g0 / 4 + q < RW / 4) row[g0 / 4 + q] = make_float4(rv[4 * q], rv[4 * q + 1], rv[4 * q + 2], rv[4 * q + 3]);
+                        if (g0 / 4 + q < RW / 4) {
+                            if (QS && g0 / 16 + q / 4 < NGF) {   // full group: [quad lane][4]
+                                const int b = 16 * (q / 4) + (q & 3);
+                                row[g0 / 4 + q] = make_float4(rv[b], rv[b + 4], rv[b + 8], rv[b + 12]);
+                            } else {
+                                row[g0 / 4 + q] = make_float4(rv[4 * q], rv[4 * q + 1], rv[4 * q + 2], rv[4 * q + 3]);
+                            }
+                        }
                     asm volatile("" ::: "memory");   // next group's loads stay behind this group's stores
                 }
             } else {
@@ -235,7 +337,14 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
 #pragma unroll
                 for (int c = 0; c < RW; c++) rv[c] = c < KC ? p_sem[(c < KC && !PF) ? c : 0] : (c == KC ? p_b : (c == KC + 1 ? p_d : 0.f));
 #pragma unroll
-                for (int q = 0; q < RW / 4; q++) row[q] = make_float4(rv[4 * q], rv[4 * q + 1], rv[4 * q + 2], rv[4 * q + 3]);
+                for (int q = 0; q < RW / 4; q++) {
+                    if (QS && q / 4 < NGF) {   // full group: [quad lane][4]
+                        const int b = 16 * (q / 4) + (q & 3);
+                        row[q] = make_float4(rv[b], rv[b + 4], rv[b + 8], rv[b + 12]);
+                    } else {
+                        row[q] = make_float4(rv[4 * q], rv[4 * q + 1], rv[4 * q + 2], rv[4 * q + 3]);
+                    }
+                }
             }
         }
         const long long tp0 = TRF_NOW();
@@ -272,6 +381,80 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int last = max(total - 1, 0);
+            if constexpr (QS) {
+                constexpr int NW = 4 * NGF + REM;
+                constexpr int NCH = KC + (BASE ? 2 : 0);   // channels that are accumulated: features, then blue, depth
+                int j_next = (int)list[0];
+                for (int k = 0; k < m; k++) {
+                    const int j = j_next;
+                    const bool valid = k < total;
+                    j_next = (int)list[min(k + 1, last)];
+                    const float4 g = s_rec[2 * j];
+                    const float4 h4 = s_rec[2 * j + 1];
+                    const float2 co = make_float2(h4.x, h4.y);
+                    const float dx = g.x - pfx, dy = g.y - pfy;
+                    const float power2 = fmaf(co.x, dy * dy, fmaf(g.w, dx * dy, g.z * (dx * dx)));
+                    const float alpha = fminf(0.99f, co.y * __builtin_amdgcn_exp2f(power2));
+                    bool contrib = valid && !done && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+                    const float test_T = T * (1.0f - alpha);
+                    if (contrib && test_T < 0.0001f) {
+                        done = true;
+                        contrib = false;
+                    }
+                    if (__ballot(contrib) == 0ull) continue;
+                    const float w = contrib ? alpha * T : 0.f;
+                    if (BASE) {
+                        C0 = fmaf(h4.z, w, C0);
+                        C1 = fmaf(h4.w, w, C1);
+                        if (MASK) Mm += w;
+                    }
+                    const float* rowf = reinterpret_cast<const float*>(s_row) + j * RW;
+                    float fq[NW];
+#pragma unroll
+                    for (int G = 0; G < NGF; G++) {
+                        const float4 f = *reinterpret_cast<const float4*>(rowf + 16 * G + 4 * (lane & 3));
+                        fq[4 * G] = f.x; fq[4 * G + 1] = f.y; fq[4 * G + 2] = f.z; fq[4 * G + 3] = f.w;
+                    }
+#pragma unroll
+                    for (int mm = 0; mm < REM; mm++) fq[4 * NGF + mm] = rowf[16 * NGF + 4 * mm + (lane & 3)];
+                    // word r (either layout) holds channels 4r .. 4r+3, channel c in quad lane c % 4; one asm block per 16 channels
+                    float dummy = 0.f;
+                    auto acc = [&](int c) -> float& { return c < KC ? S[c < KC ? c : 0] : ((BASE && c == KC) ? C2 : ((BASE && c == KC + 1) ? Dd : dummy)); };
+#pragma unroll
+                    for (int b = 0; b < (NCH + 15) / 16; b++) {
+                        const int nw = min(4, (NCH - 16 * b + 3) / 4);   // words of this block: constant after unrolling
+                        float sv[16], xv[4];
+#pragma unroll
+                        for (int i = 0; i < 16; i++) sv[i] = i < 4 * nw ? acc(16 * b + i) : 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) xv[i] = i < nw ? fq[4 * b + i] : 0.f;
+                        if (nw == 4) quad_fma_words<4>(sv, xv, w);
+                        else if (nw == 3) quad_fma_words<3>(sv, xv, w);
+                        else if (nw == 2) quad_fma_words<2>(sv, xv, w);
+                        else quad_fma_words<1>(sv, xv, w);
+#pragma unroll
+                        for (int i = 0; i < 16; i++)
+                            if (i < 4 * nw && 16 * b + i < NCH) acc(16 * b + i) = sv[i];
+                    }
+                    if (BASE) {
+                        // the broadcast runs with every lane enabled (a DPP read from a disabled lane returns nothing), then the select
+                        const float dep = quad_bcast_q(fq[(KC + 1) / 4], (KC + 1) % 4);
+                        if (contrib && T > 0.5f && test_T < 0.5f) {
+                            median_D = dep;
+                            median_at = (uint32_t)(start + j + 1);
+                        }
+                    }
+                    if (contrib) {
+                        T = test_T;
+                        last_contributor = (uint32_t)(start + j + 1);
+                    }
+#ifdef HSR_TRACE
+                    tr_iters++;
+#endif
+                }
+                TRF_ADD(tr_blend, tl0);
+                continue;
+            }
             int j_next = (int)list[0];
             for (int k = 0; k < m; k++) {
                 const int j = j_next;
