@@ -55,6 +55,14 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// orders the LDS accesses of ONE wave (stores before it are visible to the wave's loads after it); no workgroup barrier
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int SB_SLOTS = 16;        // quadrant-list entries per chunk (M dimension of the matrix-core flush)
 constexpr int SB_STRIDE = 66;       // floats per panel row
 constexpr int SB_PANEL = 64 * 17;   // floats per wave: max(16 * 66, 64 * 17 for the G transpose)
@@ -182,16 +190,19 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 else if (ch == KC + 4) v = dpo;
                 gv[g][c] = v;
             }
+        // the panel is private to the wave: a wave-level fence orders its LDS stores and loads, the four waves do not have to meet
+        // (they would wait for the slowest wave's 30-odd global loads twice per channel group)
 #pragma unroll
         for (int g = 0; g < NG; g++) {
 #pragma unroll
             for (int c = 0; c < 16; c++) panel[lane * 17 + c] = gv[g][c];
-            __syncthreads();
+            wave_lds_fence();
 #pragma unroll
             for (int m = 0; m < 16; m++) Breg[g][m] = panel[(4 * m + (lane >> 4)) * 17 + (lane & 15)];
-            __syncthreads();
+            wave_lds_fence();
         }
     }
+    __syncthreads();   // s_wmax
     const int hi_all = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     const long long tr_t1 = TR_NOW();   // end of the prologue
     (void)tr_t1;
@@ -721,7 +732,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
         }
 #pragma unroll
         for (int c = 0; c < 16; c++) panel[lane * 17 + c] = gv[c];
-        __syncthreads();
+        wave_lds_fence();   // wave-private panel: see render_bwd_sub_kernel
         if (BF) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
@@ -734,8 +745,9 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
 #pragma unroll
             for (int m = 0; m < 16; m++) Breg[g][m] = panel[(4 * m + (lane >> 4)) * 17 + (lane & 15)];
         }
-        __syncthreads();
+        wave_lds_fence();
     }
+    __syncthreads();   // s_wmax
     const int hi_all = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
 
     const float bg_dot = a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2;
