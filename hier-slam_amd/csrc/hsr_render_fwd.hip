@@ -298,8 +298,10 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
                 for (int c = 0; c < NPF; c++) pf_sink += pf_t[c];
                 const float* grow = a.semantics + (size_t)id_cur * (size_t)a.K + c0;
                 // an entry no sub-block will visit (a fifth to a third of a tile's list: the reference's 3-sigma rectangle lists
-                // splats whose alpha never reaches 1/255 on this tile) needs no row
-                if (qmask != 0u)
+                // splats whose alpha never reaches 1/255 on this tile) needs no row — except slot 0, which a group with an EMPTY list
+                // reads with weight 0 (below): an unstaged row is whatever the LDS held (the per-tile sort pads with ~0 = NaN, and
+                // NaN * 0 is NaN: found by a 300-case run of tests/test_gpu_fuzz.py)
+                if (qmask != 0u || t == 0)
 #pragma unroll
                 for (int g0 = 0; g0 < RW; g0 += 32) {
                     float rv[32];

@@ -1,6 +1,7 @@
 """Seeded random configurations through the whole rasterizer path against the oracle: ragged image sizes, any K, tiny and
 huge splats, culled points, white / coloured backgrounds.  Same checks as test_gpu_parity._compare (integers bit-exact, floats
 1e-4).  Sizes are small so that the oracle finishes in well under a second per case."""
+import os
 import zlib
 
 import numpy as np
@@ -28,11 +29,27 @@ def _cases(n=28, seed=2024):
     return out
 
 
-CASES = _cases()
+# HSR_FUZZ_CASES / HSR_FUZZ_SEED: a longer or different run of the same generator (e.g. after a kernel change: 300 cases, another seed)
+CASES = _cases(int(os.environ.get("HSR_FUZZ_CASES", "28")), int(os.environ.get("HSR_FUZZ_SEED", "2024")))
 
 
 @pytest.mark.parametrize("name,cfg", CASES, ids=[c[0] for c in CASES])
 def test_random_configuration(name, cfg):
+    W, H, P, K, kind, sm, semantic, variant, bg, behind = cfg
+    cam, sc, up = scenes.build(W, H, P, K, seed=zlib.crc32(name.encode()) % 1000, kind=kind, scale_mult=sm, bg=bg, behind_frac=behind)
+    _compare(cam, sc, up, semantic, variant, None)
+
+
+# cases of the 300-case run with seed 77 that found a bug: wide-tree forward kernels left the feature row of batch slot 0 unstaged when
+# no sub-block of the tile visits that splat, and a 16-lane group with an EMPTY list reads slot 0 with weight 0 — NaN * 0 when the LDS
+# still held the per-tile sort's ~0 padding
+_REGRESSIONS = ("108_118x88_P300_K74_aniso_x0.3", "113_195x148_P300_K31_aniso_x1", "126_128x42_P63_K74_aniso_x1",
+                "167_80x101_P300_K74_aniso_x0.3", "248_139x123_P63_K27_slam_x0.3")
+
+
+@pytest.mark.parametrize("name", _REGRESSIONS)
+def test_regressions_found_by_longer_fuzz_runs(name):
+    cfg = dict(_cases(300, 77))[name]
     W, H, P, K, kind, sm, semantic, variant, bg, behind = cfg
     cam, sc, up = scenes.build(W, H, P, K, seed=zlib.crc32(name.encode()) % 1000, kind=kind, scale_mult=sm, bg=bg, behind_frac=behind)
     _compare(cam, sc, up, semantic, variant, None)
