@@ -168,6 +168,7 @@ uint32_t hsr_sort_hist_entries(int R) { return hsr_sort_hist_entries_inline((uin
 //                 segment does not arrive in emission order (direct binning) — ping-ponging inside the tile's own
 //                 segment of the two global buffer pairs (segments of different tiles are disjoint).
 constexpr int TS_MAX = 2048;
+constexpr int TW_MAX = 1024;   // tiles of at most this many entries: one wave each, elements in registers (tile_sort_wave_kernel)
 
 __device__ __forceinline__ void ts_block_radix(uint64_t* ka, uint32_t* va, uint64_t* kb, uint32_t* vb, int r0, int n,
                                                uint32_t* hist /*[256]*/, uint32_t (*wcnt)[256], int gid_passes)
@@ -322,20 +323,21 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
     __shared__ uint32_t wcnt[4][256];
     if (composite_in == 2) {   // direct binning, tiles of at most TW_MAX entries belong to tile_sort_wave_kernel
         const uint2 rg = ranges[blockIdx.x];
-        if (rg.y - rg.x <= 512u) return;
+        if (rg.y - rg.x <= (uint32_t)TW_MAX) return;
         composite_in = 1;
     }
     block_sort_tile((int)blockIdx.x, ranges, keys, vals, keys_alt, vals_alt, gid_passes, composite_in, comp, hist, wcnt);
 }
 
-// ---- per-tile sort, one WAVE per tile, for tiles of at most 512 entries (direct binning composites) ----
+// ---- per-tile sort, one WAVE per tile, for tiles of at most 1024 entries (direct binning composites) ----
 // The block-wide network above is LDS-bound: every compare-exchange is two 8-byte reads and up to two writes with 2- to
 // 8-way bank conflicts at small strides, 45 steps for a 512-entry tile.  Here a lane keeps E = 2, 4 or 8 CONSECUTIVE
 // elements in registers (N = 64 E): the steps with stride j < E — more than half of them — are register-only, and a step
 // with j >= E exchanges whole E-element blocks with lane ^ (j / E) through a conflict-free LDS buffer (16-byte accesses,
 // lanes contiguous) and keeps the smaller or the larger element of every pair.  One wave, so no barriers at all; four
-// tiles per 256-thread workgroup.  Tiles above 512 entries are left to tile_sort_kernel (which skips the others).
-constexpr int TW_MAX = 512;   // tile_sort_kernel's composite_in == 2 branch uses the same bound
+// tiles per 256-thread workgroup.  Tiles above TW_MAX entries are left to tile_sort_kernel (which skips the others).
+// E = 16 (513..1024 entries, 32 key registers) came late in round 2: on the anisotropic and the 1920x1080 / 2M workloads most tiles
+// hold 500-1000 entries and the block-wide LDS network took 65 / 131 us per frame for them (tools/ktrace_cfg.sh).
 
 template <int E>
 __device__ __forceinline__ void wave_bitonic(uint64_t (&x)[E], int lane, ulonglong2* buf)
@@ -410,9 +412,9 @@ __global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, const uint2*
                                                              uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
                                                              uint32_t* __restrict__ vals_alt, int gid_passes, int big_too, BinDevRef ref)
 {
-    // wave phase: per wave E/2 <= 4 rows of 64 x 16 bytes; workgroup phase: comp[TS_MAX], hist[256], wcnt[4][256]
-    constexpr int RAW = TS_MAX * 8 + 256 * 4 + 4 * 256 * 4;
-    static_assert(RAW >= 4 * 4 * 64 * 16, "the wave buffers alias the workgroup arrays");
+    // wave phase: per wave E/2 <= 8 rows of 64 x 16 bytes; workgroup phase: comp[TS_MAX], hist[256], wcnt[4][256]
+    constexpr int RAW_WG = TS_MAX * 8 + 256 * 4 + 4 * 256 * 4, RAW_WV = 4 * 8 * 64 * 16;
+    constexpr int RAW = RAW_WG > RAW_WV ? RAW_WG : RAW_WV;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RAW];
     __shared__ int s_big[4];
     if (ref.base) {   // speculative forward: the arrays live where num_rendered says
@@ -430,11 +432,12 @@ __global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, const uint2*
     }
     if (lane == 0) s_big[wv] = n > TW_MAX;
     if (n > 0 && n <= TW_MAX) {
-        ulonglong2* buf = reinterpret_cast<ulonglong2*>(s_raw) + wv * (4 * 64);
+        ulonglong2* buf = reinterpret_cast<ulonglong2*>(s_raw) + wv * (8 * 64);
         const uint64_t tile_hi = (uint64_t)tile << 32;
         if (n <= 128) wave_sort_tile<2>(r0, n, lane, tile_hi, keys, vals, buf);
         else if (n <= 256) wave_sort_tile<4>(r0, n, lane, tile_hi, keys, vals, buf);
-        else wave_sort_tile<8>(r0, n, lane, tile_hi, keys, vals, buf);
+        else if (n <= 512) wave_sort_tile<8>(r0, n, lane, tile_hi, keys, vals, buf);
+        else wave_sort_tile<16>(r0, n, lane, tile_hi, keys, vals, buf);
     }
     if (!big_too) return;   // the larger tiles have a launch of their own (one workgroup per tile)
     __syncthreads();
@@ -501,10 +504,10 @@ int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStre
         tile_sort_kernel<<<T, 256, 0, stream>>>(ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8, 1, r);
         return HSR_OK;
     }
-    // tiles of <= 512 entries: one wave each, elements in registers; the larger ones by whole workgroups — in the same launch
+    // tiles of <= 1024 entries: one wave each, elements in registers; the larger ones by whole workgroups — in the same launch
     // (four tiles per workgroup, one after the other) while they are the exception, in a launch of their own (one workgroup
-    // per tile) when the previous frame averaged more than 400 entries per tile
-    const bool many_big = avg_per_tile_hint > 400;
+    // per tile) when the previous frame averaged more than 800 entries per tile
+    const bool many_big = avg_per_tile_hint > 800;
     tile_sort_wave_kernel<<<(T + 3) / 4, 256, 0, stream>>>(T, ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8,
                                                            many_big ? 0 : 1, r);
     if (many_big)
