@@ -119,9 +119,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     constexpr int NG = (NCH + 15) / 16;       // 16-channel groups
     static_assert(NG <= 2, "at most 32 direct channels per launch");
     static_assert(BATCH <= 256, "batch slots are bytes");
-    __shared__ float4 s_geo[BATCH];
-    __shared__ float2 s_co[BATCH];
-    __shared__ float4 s_col[BATCH];
+    // one 48-byte record per staged splat { x, y, A', B' | r, g, b, depth | C', opacity, -, - }: ONE address computation per visit
+    __shared__ float4 s_ent[3 * BATCH];
     __shared__ int s_id[BATCH];
     __shared__ uint16_t s_mask[BATCH];                  // sub-block mask of each staged splat
     __shared__ uint8_t s_list[4][256];
@@ -209,7 +208,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
 
     const float bg_dot = a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2;
     const float kx = (0.5f * a.W) / HSR_LOG2E, ky = (0.5f * a.H) / HSR_LOG2E;
-    float Rb = 0.f, last_h = 0.f, last_alpha = 0.f;
+    float Racc = 0.f;   // the reference's accum_rec AFTER the last accepted splat: last_alpha * last_h + (1 - last_alpha) * accum_rec (backward.cu:630-640, h = colour . dL_dpixel)
 
     // butterfly value this lane holds after row_reduce_transpose7, or -1
     const int myv = (lane & 2) ? -1 : (((lane >> 2) & 3) | ((lane & 1) << 2));
@@ -262,8 +261,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
             //   dL_dmean2D.x = kx (2 A' Sx + B' Sy), .y = ky (2 C' Sy + B' Sx)   (A', B', C': the pre-scaled conic of the staged record)
             //   dL_dconic.{x,y,w} = -0.5 {Sxx, Sxy, Syy};  columns 5, 6 (opacity, median depth) pass through
             const int ja = s_cj[wv][row];
-            const float4 gj = s_geo[ja];
-            const float cxj = s_co[ja].x;
+            const float4 gj = s_ent[3 * ja];
+            const float cxj = s_ent[3 * ja + 2].x;
             const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
             const float* sa = u7 + row * 32 + ca;
             const float* sb = u7 + row * 32 + cb;
@@ -305,6 +304,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
+        // list position of batch slot j is hi - 1 - j: "behind the last contributor" and "the median splat" as slot tests, per batch
+        const int j_first = hi - last_contributor, j_median = hi - 1 - median_at;
         const long long ts = TR_NOW();
         (void)ts;
         __syncthreads();
@@ -315,9 +316,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                     ((uint32_t)((mask & 0xF000u) != 0u) << 3);
             s_mask[t] = (uint16_t)mask;
             s_id[t] = id_cur;
-            s_geo[t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
-            s_co[t] = make_float2((-0.5f * HSR_LOG2E) * p_co.z, p_co.w);
-            s_col[t] = make_float4(p_r, p_g, p_b, p_d);
+            s_ent[3 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
+            s_ent[3 * t + 1] = make_float4(p_r, p_g, p_b, p_d);
+            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, 0.f, 0.f);
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
@@ -347,8 +348,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 s_cid[wv][l16] = s_id[jr];
             }
             clear_chunk();
-            const int iters = max(max(__popc((uint32_t)ball & 0xFFFFu), __popc((uint32_t)(ball >> 16) & 0xFFFFu)),
-                                  max(__popc((uint32_t)(ball >> 32) & 0xFFFFu), __popc((uint32_t)(ball >> 48))));
+            // wave-uniform (readfirstlane: the loop counter then lives in a scalar register, not in a VALU down-counter)
+            const int iters = __builtin_amdgcn_readfirstlane(max(max(__popc((uint32_t)ball & 0xFFFFu), __popc((uint32_t)(ball >> 16) & 0xFFFFu)),
+                                                                 max(__popc((uint32_t)(ball >> 32) & 0xFFFFu), __popc((uint32_t)(ball >> 48)))));
             uint32_t todo = (uint32_t)(ball >> (16 * gq)) & 0xFFFFu;   // this group's entries, visited in list order
             int r_next = todo ? __builtin_ctz(todo) : 0;
             int j_next = s_cj[wv][r_next];
@@ -358,17 +360,17 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 todo &= todo - 1u;
                 r_next = todo ? __builtin_ctz(todo) : 0;
                 j_next = s_cj[wv][r_next];
-                const float4 g = s_geo[j];
-                const float2 co = s_co[j];
-                const float4 cd = s_col[j];
+                const float4* ent = &s_ent[3 * j];
+                const float4 g = ent[0];
+                const float4 cd = ent[1];
+                const float2 co = *reinterpret_cast<const float2*>(&ent[2]);
                 asm volatile("" ::"v"(cd.x), "v"(cd.y), "v"(cd.z), "v"(cd.w));
-                const int pos = hi - 1 - j;
                 const float dx = g.x - pfx, dy = g.y - pfy;
                 const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
                 const float power2 = fmaf(co.x, dyy, fmaf(g.w, dxy, g.z * dxx));
                 const float G = __builtin_amdgcn_exp2f(power2);
                 const float alpha = fminf(0.99f, co.y * G);
-                const bool active = valid && pos < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+                const bool active = valid && j >= j_first && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
 #ifdef HSR_TRACE
                 tr_iters++;
 #endif
@@ -383,7 +385,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 if (valid) panel[r * SB_STRIDE + lane] = w;
 
                 const float h = fmaf(cd.x, dpx0, fmaf(cd.y, dpx1, fmaf(cd.z, dpx2, fmaf(cd.w, dpd, dpo))));
-                const float Rn = fmaf(last_alpha, last_h - Rb, Rb);
+                const float Rn = Racc;
                 float dL_dalpha = (h - Rn) * test_T;
                 dL_dalpha += (-T_final * inv_one_m_a) * bg_dot;
                 const float Gs = active ? G : 0.f;
@@ -400,11 +402,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 v[3] = q * dxy;
                 v[4] = q * dyy;
                 v[5] = gda;
-                v[6] = (active && pos == median_at) ? dpm : 0.f;
+                v[6] = (active && j == j_median) ? dpm : 0.f;
                 if (active) {
-                    Rb = Rn;
-                    last_h = h;
-                    last_alpha = alpha;
+                    Racc = fmaf(alpha, h - Rn, Rn);   // evaluated now instead of at the next visit: one select instead of three
                     T = test_T;
                 }
                 const float total7 = row_reduce_transpose7(v, lane);
@@ -445,9 +445,8 @@ template <int BATCH>
 __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
 {
     static_assert(BATCH <= 256, "batch slots are bytes");
-    __shared__ float4 s_geo[BATCH];
-    __shared__ float2 s_co[BATCH];
-    __shared__ float4 s_col[BATCH];
+    // one 48-byte record per staged splat { x, y, A', B' | r, g, b, depth | C', opacity, -, - }: ONE address computation per visit
+    __shared__ float4 s_ent[3 * BATCH];
     __shared__ int s_id[BATCH];
     __shared__ uint16_t s_mask[BATCH];                  // sub-block mask of each staged splat
     __shared__ uint8_t s_list[4][256];
@@ -494,7 +493,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
 
     const float bg_dot = a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2;
     const float kx = (0.5f * a.W) / HSR_LOG2E, ky = (0.5f * a.H) / HSR_LOG2E;
-    float Rb = 0.f, last_h = 0.f, last_alpha = 0.f;
+    float Racc = 0.f;   // the reference's accum_rec AFTER the last accepted splat: last_alpha * last_h + (1 - last_alpha) * accum_rec (backward.cu:630-640, h = colour . dL_dpixel)
 
     // butterfly value this lane holds after row_reduce_transpose7, or -1
     const int myv = (lane & 2) ? -1 : (((lane >> 2) & 3) | ((lane & 1) << 2));
@@ -512,8 +511,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
         for (int pass = 0; pass < 2; pass++) {
             const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
             const int ja = s_cj[wv][row];
-            const float4 gj = s_geo[ja];
-            const float cxj = s_co[ja].x;
+            const float4 gj = s_ent[3 * ja];
+            const float cxj = s_ent[3 * ja + 2].x;
             const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
             const float* sa = u7 + row * 32 + ca;
             const float* sb = u7 + row * 32 + cb;
@@ -555,6 +554,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
+        // list position of batch slot j is hi - 1 - j: "behind the last contributor" and "the median splat" as slot tests, per batch
+        const int j_first = hi - last_contributor, j_median = hi - 1 - median_at;
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
@@ -563,9 +564,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                     ((uint32_t)((mask & 0xF000u) != 0u) << 3);
             s_mask[t] = (uint16_t)mask;
             s_id[t] = id_cur;
-            s_geo[t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
-            s_co[t] = make_float2((-0.5f * HSR_LOG2E) * p_co.z, p_co.w);
-            s_col[t] = make_float4(p_r, p_g, p_b, p_d);
+            s_ent[3 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
+            s_ent[3 * t + 1] = make_float4(p_r, p_g, p_b, p_d);
+            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, 0.f, 0.f);
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
@@ -592,8 +593,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                 s_cid[wv][l16] = s_id[jr];
             }
             clear_chunk();
-            const int iters = max(max(__popc((uint32_t)ball & 0xFFFFu), __popc((uint32_t)(ball >> 16) & 0xFFFFu)),
-                                  max(__popc((uint32_t)(ball >> 32) & 0xFFFFu), __popc((uint32_t)(ball >> 48))));
+            // wave-uniform (readfirstlane: the loop counter then lives in a scalar register, not in a VALU down-counter)
+            const int iters = __builtin_amdgcn_readfirstlane(max(max(__popc((uint32_t)ball & 0xFFFFu), __popc((uint32_t)(ball >> 16) & 0xFFFFu)),
+                                                                 max(__popc((uint32_t)(ball >> 32) & 0xFFFFu), __popc((uint32_t)(ball >> 48)))));
             uint32_t todo = (uint32_t)(ball >> (16 * gq)) & 0xFFFFu;   // this group's entries, visited in list order
             int r_next = todo ? __builtin_ctz(todo) : 0;
             int j_next = s_cj[wv][r_next];
@@ -603,17 +605,17 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                 todo &= todo - 1u;
                 r_next = todo ? __builtin_ctz(todo) : 0;
                 j_next = s_cj[wv][r_next];
-                const float4 g = s_geo[j];
-                const float2 co = s_co[j];
-                const float4 cd = s_col[j];
+                const float4* ent = &s_ent[3 * j];
+                const float4 g = ent[0];
+                const float4 cd = ent[1];
+                const float2 co = *reinterpret_cast<const float2*>(&ent[2]);
                 asm volatile("" ::"v"(cd.x), "v"(cd.y), "v"(cd.z), "v"(cd.w));
-                const int pos = hi - 1 - j;
                 const float dx = g.x - pfx, dy = g.y - pfy;
                 const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
                 const float power2 = fmaf(co.x, dyy, fmaf(g.w, dxy, g.z * dxx));
                 const float G = __builtin_amdgcn_exp2f(power2);
                 const float alpha = fminf(0.99f, co.y * G);
-                const bool active = valid && pos < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+                const bool active = valid && j >= j_first && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
                 if (__ballot(active) == 0ull) continue;
 
                 const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -621,7 +623,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                 const float w = active ? alpha * test_T : 0.f;
 
                 const float h = fmaf(cd.x, dpx0, fmaf(cd.y, dpx1, fmaf(cd.z, dpx2, fmaf(cd.w, dpd, dpo))));
-                const float Rn = fmaf(last_alpha, last_h - Rb, Rb);
+                const float Rn = Racc;
                 float dL_dalpha = (h - Rn) * test_T;
                 dL_dalpha += (-T_final * inv_one_m_a) * bg_dot;
                 const float Gs = active ? G : 0.f;
@@ -634,11 +636,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                 v[3] = q * dxy;
                 v[4] = q * dyy;
                 v[5] = gda;
-                v[6] = fmaf(w, dpd, (active && pos == median_at) ? dpm : 0.f);   // depth: direct sum + median term
+                v[6] = fmaf(w, dpd, (active && j == j_median) ? dpm : 0.f);   // depth: direct sum + median term
                 if (active) {
-                    Rb = Rn;
-                    last_h = h;
-                    last_alpha = alpha;
+                    Racc = fmaf(alpha, h - Rn, Rn);   // evaluated now instead of at the next visit: one select instead of three
                     T = test_T;
                 }
                 const float total7 = row_reduce_transpose7(v, lane);
@@ -662,9 +662,8 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
     constexpr int STRIDE = BF ? 68 : SB_STRIDE;   // floats per panel row; 68: rows 16-byte aligned, b128 reads of 16 rows hit 64 banks
     static_assert(SB_SLOTS * STRIDE <= SB_PANEL, "panel");
     static_assert(BATCH <= 256, "batch slots are bytes");
-    __shared__ float4 s_geo[BATCH];
-    __shared__ float2 s_co[BATCH];
-    __shared__ float4 s_col[BATCH];
+    // one 48-byte record per staged splat { x, y, A', B' | r, g, b, depth | C', opacity, -, - }: ONE address computation per visit
+    __shared__ float4 s_ent[3 * BATCH];
     __shared__ int s_id[BATCH];
     __shared__ uint16_t s_mask[BATCH];                  // sub-block mask of each staged splat
     __shared__ uint8_t s_list[4][256];
@@ -752,7 +751,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
 
     const float bg_dot = a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2;
     const float kx = (0.5f * a.W) / HSR_LOG2E, ky = (0.5f * a.H) / HSR_LOG2E;
-    float Rb = 0.f, last_h = 0.f, last_alpha = 0.f;
+    float Racc = 0.f;   // the reference's accum_rec AFTER the last accepted splat: last_alpha * last_h + (1 - last_alpha) * accum_rec (backward.cu:630-640, h = colour . dL_dpixel)
 
     // butterfly value this lane holds after row_reduce_transpose7, or -1
     const int myv = (lane & 2) ? -1 : (((lane >> 2) & 3) | ((lane & 1) << 2));
@@ -829,8 +828,8 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
         for (int pass = 0; pass < (BASE ? 2 : 0); pass++) {
             const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
             const int ja = s_cj[wv][row];
-            const float4 gj = s_geo[ja];
-            const float cxj = s_co[ja].x;
+            const float4 gj = s_ent[3 * ja];
+            const float cxj = s_ent[3 * ja + 2].x;
             const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
             const float* sa = u7 + row * 32 + ca;
             const float* sb = u7 + row * 32 + cb;
@@ -872,6 +871,8 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
+        // list position of batch slot j is hi - 1 - j: "behind the last contributor" and "the median splat" as slot tests, per batch
+        const int j_first = hi - last_contributor, j_median = hi - 1 - median_at;
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
@@ -880,9 +881,9 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
                     ((uint32_t)((mask & 0xF000u) != 0u) << 3);
             s_mask[t] = (uint16_t)mask;
             s_id[t] = id_cur;
-            s_geo[t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
-            s_co[t] = make_float2((-0.5f * HSR_LOG2E) * p_co.z, p_co.w);
-            s_col[t] = make_float4(p_r, p_g, p_b, p_d);
+            s_ent[3 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
+            s_ent[3 * t + 1] = make_float4(p_r, p_g, p_b, p_d);
+            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, 0.f, 0.f);
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
@@ -909,8 +910,9 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
                 s_cid[wv][l16] = s_id[jr];
             }
             clear_chunk();
-            const int iters = max(max(__popc((uint32_t)ball & 0xFFFFu), __popc((uint32_t)(ball >> 16) & 0xFFFFu)),
-                                  max(__popc((uint32_t)(ball >> 32) & 0xFFFFu), __popc((uint32_t)(ball >> 48))));
+            // wave-uniform (readfirstlane: the loop counter then lives in a scalar register, not in a VALU down-counter)
+            const int iters = __builtin_amdgcn_readfirstlane(max(max(__popc((uint32_t)ball & 0xFFFFu), __popc((uint32_t)(ball >> 16) & 0xFFFFu)),
+                                                                 max(__popc((uint32_t)(ball >> 32) & 0xFFFFu), __popc((uint32_t)(ball >> 48)))));
             uint32_t todo = (uint32_t)(ball >> (16 * gq)) & 0xFFFFu;   // this group's entries, visited in list order
             int r_next = todo ? __builtin_ctz(todo) : 0;
             int j_next = s_cj[wv][r_next];
@@ -920,17 +922,17 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
                 todo &= todo - 1u;
                 r_next = todo ? __builtin_ctz(todo) : 0;
                 j_next = s_cj[wv][r_next];
-                const float4 g = s_geo[j];
-                const float2 co = s_co[j];
-                const float4 cd = s_col[j];
+                const float4* ent = &s_ent[3 * j];
+                const float4 g = ent[0];
+                const float4 cd = ent[1];
+                const float2 co = *reinterpret_cast<const float2*>(&ent[2]);
                 asm volatile("" ::"v"(cd.x), "v"(cd.y), "v"(cd.z), "v"(cd.w));
-                const int pos = hi - 1 - j;
                 const float dx = g.x - pfx, dy = g.y - pfy;
                 const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
                 const float power2 = fmaf(co.x, dyy, fmaf(g.w, dxy, g.z * dxx));
                 const float G = __builtin_amdgcn_exp2f(power2);
                 const float alpha = fminf(0.99f, co.y * G);
-                const bool active = valid && pos < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+                const bool active = valid && j >= j_first && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
                 if (__ballot(active) == 0ull) continue;
 
                 const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -943,7 +945,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
                     continue;
                 }
                 const float h = fmaf(cd.x, dpx0, fmaf(cd.y, dpx1, fmaf(cd.z, dpx2, fmaf(cd.w, dpd, dpo))));
-                const float Rn = fmaf(last_alpha, last_h - Rb, Rb);
+                const float Rn = Racc;
                 float dL_dalpha = (h - Rn) * test_T;
                 dL_dalpha += (-T_final * inv_one_m_a) * bg_dot;
                 const float Gs = active ? G : 0.f;
@@ -956,11 +958,9 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
                 v[3] = q * dxy;
                 v[4] = q * dyy;
                 v[5] = gda;
-                v[6] = (active && pos == median_at) ? dpm : 0.f;
+                v[6] = (active && j == j_median) ? dpm : 0.f;
                 if (active) {
-                    Rb = Rn;
-                    last_h = h;
-                    last_alpha = alpha;
+                    Racc = fmaf(alpha, h - Rn, Rn);   // evaluated now instead of at the next visit: one select instead of three
                     T = test_T;
                 }
                 const float total7 = row_reduce_transpose7(v, lane);
