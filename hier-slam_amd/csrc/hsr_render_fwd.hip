@@ -44,23 +44,6 @@ extern "C" int hsr_debug_read_trace_fwd(unsigned long long* host, int n)
 
 namespace {
 
-// x of lane Q of the caller's quad (lanes 4i .. 4i+3), as a DPP operand: folds into the consuming v_fmac_f32 (no instruction of its own)
-template <int Q>
-__device__ __forceinline__ float quad_bcast(float x)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), Q * 0x55, 0xf, 0xf, true));
-}
-
-__device__ __forceinline__ float quad_bcast_q(float x, int q)   // q: a constant after unrolling
-{
-    switch (q) {
-    case 0: return quad_bcast<0>(x);
-    case 1: return quad_bcast<1>(x);
-    case 2: return quad_bcast<2>(x);
-    default: return quad_bcast<3>(x);
-    }
-}
-
 // s[4 r + q] += x[r](quad lane q) * w for r < W, q < 4: the value travels in the FMA's own DPP operand.  Written as ONE asm block per
 // group of up to 16 channels because hipcc keeps its packed FMAs and materialises every broadcast with a v_mov_b32_dpp of its own (two
 // instructions per channel instead of one); the leading s_nop covers gfx9's "VALU write -> DPP read" wait states whatever the
@@ -201,7 +184,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
-    float C0 = 0, C1 = 0, C2 = 0, Dd = 0, Mm = 0, median_D = 15.0f;
+    float C0 = 0, C1 = 0, C2 = 0, Dd = 0, Mm = 0;
     uint32_t median_at = 0;   // 1 + list position of the splat at which T crossed 0.5 (ImgState::median_pos)
     float S[KC > 0 ? KC : 1];
 #pragma unroll
@@ -439,12 +422,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
                             if (i < 4 * nw && 16 * b + i < NCH) acc(16 * b + i) = sv[i];
                     }
                     if (BASE) {
-                        // the broadcast runs with every lane enabled (a DPP read from a disabled lane returns nothing), then the select
-                        const float dep = quad_bcast_q(fq[(KC + 1) / 4], (KC + 1) % 4);
-                        if (contrib && T > 0.5f && test_T < 0.5f) {
-                            median_D = dep;
-                            median_at = (uint32_t)(start + j + 1);
-                        }
+                        if (contrib && T > 0.5f && test_T < 0.5f) median_at = (uint32_t)(start + j + 1);   // its depth: epilogue
                     }
                     if (contrib) {
                         T = test_T;
@@ -494,10 +472,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
                             else if (BASE && c == KC) C2 = fmaf(fv[i], w, C2);
                             else if (BASE && c == KC + 1) {
                                 Dd = fmaf(fv[i], w, Dd);
-                                if (contrib && T > 0.5f && test_T < 0.5f) {
-                                    median_D = fv[i];
-                                    median_at = (uint32_t)(start + j + 1);
-                                }
+                                if (contrib && T > 0.5f && test_T < 0.5f) median_at = (uint32_t)(start + j + 1);   // its depth: epilogue
                             }
                         }
                     }
@@ -553,10 +528,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
                             else if (BASE && c == KC) C2 = fmaf(fv[i], w, C2);
                             else if (BASE && c == KC + 1) {
                                 Dd = fmaf(fv[i], w, Dd);
-                                if (contrib && T > 0.5f && test_T < 0.5f) {
-                                    median_D = fv[i];
-                                    median_at = (uint32_t)(start + j + 1);
-                                }
+                                if (contrib && T > 0.5f && test_T < 0.5f) median_at = (uint32_t)(start + j + 1);   // its depth: epilogue
                             }
                         }
                     }
@@ -583,6 +555,10 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
             a.out_color[N + pix_id] = C1;
             a.out_color[2 * N + pix_id] = C2;
             a.out_depth[pix_id] = Dd;
+            // median depth = depth of the splat at which T crossed 0.5 (forward.cu:511-515, default 15.0 :450): the loop only records
+            // WHERE (one select per visit instead of two), the value is the staged record's depth, fetched once here
+            float median_D = 15.0f;
+            if (median_at != 0u) median_D = a.rec[4 * (size_t)a.point_list[range.x + median_at - 1u]].z;
             a.out_median_depth[pix_id] = median_D;
             a.out_opacity[pix_id] = 1.0f - T;
             if (MASK) a.out_mask[pix_id] = Mm;
