@@ -25,7 +25,7 @@ def child(n):
     for i in range(n):
         W, H = int(g.integers(17, 260)), int(g.integers(17, 200))
         P = int(g.choice([50, 400, 1500, 4000]))
-        K = int(g.choice([0, 5, 26]))
+        K = int(g.choice([0, 5, 26, 40, 74]))
         kind = str(g.choice(["slam", "aniso"]))
         sm = float(g.choice([0.2, 1.0, 3.0, 10.0, 40.0]))
         cam, sc, up = scenes.build(W, H, P, K, seed=1000 + i, kind=kind, scale_mult=sm)
