@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     __shared__ int s_wmax[4];
     __shared__ float s_panel[4][SB_PANEL];
     __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
-    __shared__ int s_cid[4][SB_SLOTS];                  // Gaussian id of each chunk row
+    __shared__ uint32_t s_cid[4][SB_SLOTS];             // packed-row offset (Gaussian id x row stride) of each chunk row
     __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * (lane >> 4) + r;
-            const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride;
+            const uint32_t base = s_cid[wv][row];
 #pragma unroll
             for (int g = 0; g < NG; g++)
                 if (row < nrows && colg[g] >= 0 && acc[g][r] != 0.f && !(a.debug_flags & 1))
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
             const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
             const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
             const float val = fmaf(wb, tb, wa * ta);
-            const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride + (uint32_t)vi;
+            const uint32_t base = s_cid[wv][row] + (uint32_t)vi;
             if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
     };
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
             const uint64_t ball = __ballot(touch);
             if (gq == 0) {
                 s_cj[wv][l16] = (uint8_t)jr;
-                s_cid[wv][l16] = s_id[jr];
+                s_cid[wv][l16] = (uint32_t)s_id[jr] * (uint32_t)a.grow_stride;   // once per chunk row, not once per emitted register
             }
             clear_chunk();
             // wave-uniform (readfirstlane: the loop counter then lives in a scalar register, not in a VALU down-counter)
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
     __shared__ uint8_t s_flat[4][256];
     __shared__ int s_wmax[4];
     __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
-    __shared__ int s_cid[4][SB_SLOTS];                  // Gaussian id of each chunk row
+    __shared__ uint32_t s_cid[4][SB_SLOTS];             // packed-row offset (Gaussian id x row stride) of each chunk row
     __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
             const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
             const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
             const float val = fmaf(wb, tb, wa * ta);
-            const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride + (uint32_t)vi;
+            const uint32_t base = s_cid[wv][row] + (uint32_t)vi;
             if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
     };
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
             const uint64_t ball = __ballot(touch);
             if (gq == 0) {
                 s_cj[wv][l16] = (uint8_t)jr;
-                s_cid[wv][l16] = s_id[jr];
+                s_cid[wv][l16] = (uint32_t)s_id[jr] * (uint32_t)a.grow_stride;   // once per chunk row, not once per emitted register
             }
             clear_chunk();
             // wave-uniform (readfirstlane: the loop counter then lives in a scalar register, not in a VALU down-counter)
@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
     __shared__ int s_wmax[4];
     __shared__ float s_panel[4][SB_PANEL];
     __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
-    __shared__ int s_cid[4][SB_SLOTS];                  // Gaussian id of each chunk row
+    __shared__ uint32_t s_cid[4][SB_SLOTS];             // packed-row offset (Gaussian id x row stride) of each chunk row
     __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
@@ -817,7 +817,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * (lane >> 4) + r;
-            const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride;
+            const uint32_t base = s_cid[wv][row];
 #pragma unroll
             for (int g = 0; g < NG; g++)
                 if (row < nrows && colg[g] >= 0 && acc[g][r] != 0.f && !(a.debug_flags & 1))
@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
             const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
             const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
             const float val = fmaf(wb, tb, wa * ta);
-            const uint32_t base = (uint32_t)s_cid[wv][row] * (uint32_t)a.grow_stride + (uint32_t)vi;
+            const uint32_t base = s_cid[wv][row] + (uint32_t)vi;
             if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
     };
@@ -907,7 +907,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
             const uint64_t ball = __ballot(touch);
             if (gq == 0) {
                 s_cj[wv][l16] = (uint8_t)jr;
-                s_cid[wv][l16] = s_id[jr];
+                s_cid[wv][l16] = (uint32_t)s_id[jr] * (uint32_t)a.grow_stride;   // once per chunk row, not once per emitted register
             }
             clear_chunk();
             // wave-uniform (readfirstlane: the loop counter then lives in a scalar register, not in a VALU down-counter)
