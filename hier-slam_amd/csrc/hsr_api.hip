@@ -344,7 +344,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
 
     RenderFwdArgs ra;
     ra.W = W; ra.H = H; ra.K = in.semantic ? in.K : 0; ra.semantic = in.semantic;
-    ra.ranges = im.ranges; ra.point_list = nullptr; ra.means2D = g.means2D; ra.conic_opacity = g.conic_opacity;
+    ra.ranges = im.ranges; ra.point_list = nullptr; ra.masks = nullptr; ra.means2D = g.means2D; ra.conic_opacity = g.conic_opacity;
     ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb; ra.semantics = in.semantics;
     ra.rec = g.rec;
     ra.final_T = im.final_T; ra.n_contrib = im.n_contrib; ra.median_pos = im.median_pos;
@@ -444,6 +444,7 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     HSR_LAUNCH_CHECK(in.debug, stream);
 
     ra.point_list = b.vals;
+    ra.masks = b.vals_unsorted;   // free after the sort: the staging phase leaves the sub-block masks there for the backward
     {
         StageTimer tm(HSR_STAGE_FWD_RENDER, stream);
         hsr_launch_render_forward(ra, stream);
@@ -585,7 +586,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
             static const int dbg = hsr_ablate_env("HSR_DEBUG_FLAGS") ? atoi(hsr_ablate_env("HSR_DEBUG_FLAGS")) : 0;
             ra.debug_flags = dbg;   // 0 in the product build
         }
-        ra.bg = in.background; ra.ranges = im.ranges; ra.point_list = b.vals; ra.means2D = g.means2D;
+        ra.bg = in.background; ra.ranges = im.ranges; ra.point_list = b.vals; ra.masks = b.vals_unsorted; ra.means2D = g.means2D;
         ra.conic_opacity = g.conic_opacity; ra.depths = g.depths; ra.colors = in.colors_precomp ? in.colors_precomp : g.rgb;
         ra.rec = g.rec;
         ra.final_T = im.final_T; ra.n_contrib = im.n_contrib; ra.median_pos = im.median_pos;

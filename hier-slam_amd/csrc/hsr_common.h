@@ -156,6 +156,8 @@ struct RenderFwdArgs {
     int W, H, K, semantic;
     const uint2* ranges;
     const uint32_t* point_list;
+    uint32_t* masks;         // [R], parallel to point_list: the 16-bit sub-block mask of every list entry the forward stages (hsr_tile_common.h:
+                             // subblock_mask), kept for the backward in BinState::vals_unsorted — free once the per-tile sort has run
     const float2* means2D;
     const float4* conic_opacity;
     const float* depths;
@@ -184,6 +186,7 @@ struct RenderBwdArgs {
     const float* bg;  // device [3]
     const uint2* ranges;
     const uint32_t* point_list;
+    const uint32_t* masks;   // [R] sub-block masks written by the forward's staging (RenderFwdArgs::masks)
     const float2* means2D;
     const float4* conic_opacity;
     const float* depths;

@@ -51,7 +51,17 @@ namespace {
 // s_waitcnt would also have to sit out every atomic issued in between (loads, stores and atomics retire through one in-order counter).
 #define HSR_SETTLE_STAGING()                                                                                                   \
     asm volatile("" ::"v"(id_next), "v"(p_xy.x), "v"(p_xy.y), "v"(p_co.x), "v"(p_co.y), "v"(p_co.z), "v"(p_co.w), "v"(p_r), "v"(p_g), \
-                 "v"(p_b), "v"(p_d))
+                 "v"(p_b), "v"(p_d), "v"(p_mask))
+
+// The forward's staging phase leaves the 16-bit sub-block mask of every list entry it stages in RenderBwdArgs::masks (the backward
+// stages a subset of those entries: it stops at the tile's largest n_contrib): one 4-byte load per entry instead of ~460 instructions of
+// subblock_mask per staged splat, a tenth of this kernel's VALU work.  The diagnostic build keeps deriving it (its experimental forward
+// kernels do not write masks, and HSR_DEBUG_FLAGS=16 switches the culling off per call).
+#ifdef HSR_ABLATE
+constexpr bool SAVED_MASKS = false;
+#else
+constexpr bool SAVED_MASKS = true;
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -281,11 +291,13 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     float2 p_xy = {0, 0};
     float4 p_co = {0, 0, 0, 0};
     float p_r = 0, p_g = 0, p_b = 0, p_d = 0;
+    uint32_t p_mask = 0u;
     // unconditional, clamped staging loads, the id of the batch after next requested before the next batch's records: see
     // render_fwd_kernel (a load inside a divergent `if`, or into a register the loads before it took their addresses from, is waited
     // for where it is issued — and the (rec == NULL) fallback kept three of these values in a scratch slot).  a.rec is never NULL.
     const int n_list = (int)(range.y - range.x);
     auto fetch_id = [&](int hi) -> int { return (int)a.point_list[range.x + min(max(hi - 1 - t, 0), max(n_list - 1, 0))]; };
+    auto fetch_mask = [&](int hi) -> uint32_t { return SAVED_MASKS ? a.masks[range.x + min(max(hi - 1 - t, 0), max(n_list - 1, 0))] : 0u; };
     auto load_record = [&](int id_of) {
         const size_t id = (size_t)id_of;
         id_cur = id_of;
@@ -300,6 +312,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
         const int id0 = fetch_id(hi_all);
         id_next = fetch_id(hi_all - BATCH);
         load_record(id0);
+        p_mask = fetch_mask(hi_all);
     }
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
@@ -311,7 +324,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
-            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
+            const uint32_t mask = SAVED_MASKS ? p_mask
+                                              : subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
             qmask = (uint32_t)((mask & 0xFu) != 0u) | ((uint32_t)((mask & 0xF0u) != 0u) << 1) | ((uint32_t)((mask & 0xF00u) != 0u) << 2) |
                     ((uint32_t)((mask & 0xF000u) != 0u) << 3);
             s_mask[t] = (uint16_t)mask;
@@ -326,6 +340,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
             const int id_use = id_next;            // ids of the next batch, requested a whole batch ago
             id_next = fetch_id(hi - 2 * BATCH);
             load_record(id_use);
+            p_mask = fetch_mask(hi - BATCH);
         }
         TR_ADD(tr_stage, ts);
         if (hi - cnt >= wmax) {   // this wave's pixels all stopped in front of this batch
@@ -531,11 +546,13 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
     float2 p_xy = {0, 0};
     float4 p_co = {0, 0, 0, 0};
     float p_r = 0, p_g = 0, p_b = 0, p_d = 0;
+    uint32_t p_mask = 0u;
     // unconditional, clamped staging loads, the id of the batch after next requested before the next batch's records: see
     // render_fwd_kernel (a load inside a divergent `if`, or into a register the loads before it took their addresses from, is waited
     // for where it is issued — and the (rec == NULL) fallback kept three of these values in a scratch slot).  a.rec is never NULL.
     const int n_list = (int)(range.y - range.x);
     auto fetch_id = [&](int hi) -> int { return (int)a.point_list[range.x + min(max(hi - 1 - t, 0), max(n_list - 1, 0))]; };
+    auto fetch_mask = [&](int hi) -> uint32_t { return SAVED_MASKS ? a.masks[range.x + min(max(hi - 1 - t, 0), max(n_list - 1, 0))] : 0u; };
     auto load_record = [&](int id_of) {
         const size_t id = (size_t)id_of;
         id_cur = id_of;
@@ -550,6 +567,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
         const int id0 = fetch_id(hi_all);
         id_next = fetch_id(hi_all - BATCH);
         load_record(id0);
+        p_mask = fetch_mask(hi_all);
     }
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
@@ -559,7 +577,8 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
-            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
+            const uint32_t mask = SAVED_MASKS ? p_mask
+                                              : subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
             qmask = (uint32_t)((mask & 0xFu) != 0u) | ((uint32_t)((mask & 0xF0u) != 0u) << 1) | ((uint32_t)((mask & 0xF00u) != 0u) << 2) |
                     ((uint32_t)((mask & 0xF000u) != 0u) << 3);
             s_mask[t] = (uint16_t)mask;
@@ -574,6 +593,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
             const int id_use = id_next;            // ids of the next batch, requested a whole batch ago
             id_next = fetch_id(hi - 2 * BATCH);
             load_record(id_use);
+            p_mask = fetch_mask(hi - BATCH);
         }
         if (hi - cnt >= wmax) {   // this wave's pixels all stopped in front of this batch
             HSR_SETTLE_STAGING();
@@ -848,11 +868,13 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
     float2 p_xy = {0, 0};
     float4 p_co = {0, 0, 0, 0};
     float p_r = 0, p_g = 0, p_b = 0, p_d = 0;
+    uint32_t p_mask = 0u;
     // unconditional, clamped staging loads, the id of the batch after next requested before the next batch's records: see
     // render_fwd_kernel (a load inside a divergent `if`, or into a register the loads before it took their addresses from, is waited
     // for where it is issued — and the (rec == NULL) fallback kept three of these values in a scratch slot).  a.rec is never NULL.
     const int n_list = (int)(range.y - range.x);
     auto fetch_id = [&](int hi) -> int { return (int)a.point_list[range.x + min(max(hi - 1 - t, 0), max(n_list - 1, 0))]; };
+    auto fetch_mask = [&](int hi) -> uint32_t { return SAVED_MASKS ? a.masks[range.x + min(max(hi - 1 - t, 0), max(n_list - 1, 0))] : 0u; };
     auto load_record = [&](int id_of) {
         const size_t id = (size_t)id_of;
         id_cur = id_of;
@@ -867,6 +889,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
         const int id0 = fetch_id(hi_all);
         id_next = fetch_id(hi_all - BATCH);
         load_record(id0);
+        p_mask = fetch_mask(hi_all);
     }
 
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
@@ -876,7 +899,8 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
         __syncthreads();
         uint32_t qmask = 0u;
         if (t < cnt) {
-            const uint32_t mask = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
+            const uint32_t mask = SAVED_MASKS ? p_mask
+                                              : subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
             qmask = (uint32_t)((mask & 0xFu) != 0u) | ((uint32_t)((mask & 0xF0u) != 0u) << 1) | ((uint32_t)((mask & 0xF00u) != 0u) << 2) |
                     ((uint32_t)((mask & 0xF000u) != 0u) << 3);
             s_mask[t] = (uint16_t)mask;
@@ -891,6 +915,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
             const int id_use = id_next;            // ids of the next batch, requested a whole batch ago
             id_next = fetch_id(hi - 2 * BATCH);
             load_record(id_use);
+            p_mask = fetch_mask(hi - BATCH);
         }
         if (hi - cnt >= wmax) {   // this wave's pixels all stopped in front of this batch
             HSR_SETTLE_STAGING();

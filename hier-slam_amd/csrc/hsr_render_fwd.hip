@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
         BinState bs;
         if (!hsr_bin_resolve(a.bin, *a.bin.R_dev, &bs)) return;
         a.point_list = bs.vals;
+        a.masks = bs.vals_unsorted;
     }
     const TileGeom tg = SUB ? tile_geom_sub(tile, a.W, a.H, t) : tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
@@ -268,8 +269,9 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ?
         const int cnt = min(BATCH, n - start);
         uint32_t qmask = 0u;
         if (t < cnt) {
-            qmask = SUB ? subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16))
-                        : quadrant_mask_exact(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0);
+            const uint32_t mask16 = subblock_mask(p_xy.x, p_xy.y, p_co.x, p_co.y, p_co.z, p_co.w, tile_x0, tile_y0, !(a.debug_flags & 16));
+            qmask = SUB ? mask16 : quadrant_bits(mask16);
+            a.masks[range.x + start + t] = mask16;   // the backward stages the same entries: it reads the mask instead of deriving it again
             s_rec[2 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
             s_rec[2 * t + 1] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, p_r, p_g);
             float4* row = &s_row[t * (RW / 4)];

@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(256, 2) render_fwd_wide_kernel(RenderFwdArgs a
         BinState bs;
         if (!hsr_bin_resolve(a.bin, *a.bin.R_dev, &bs)) return;
         a.point_list = bs.vals;
+        a.masks = bs.vals_unsorted;
     }
     const TileGeom tg = tile_geom(tile, a.W, a.H, t);
     const bool inside = tg.inside;
@@ -152,7 +153,11 @@ __global__ void __launch_bounds__(256, 2) render_fwd_wide_kernel(RenderFwdArgs a
                 // r, g, b, depth directly behind the semantics (columns the row copies never touch)
                 float* dst = &s_feat[e * FS + K];
                 dst[0] = cr; dst[1] = cg; dst[2] = cb; dst[3] = dep;
-                if (live) qmask = quadrant_mask_exact(xy.x, xy.y, co.x, co.y, co.z, co.w, tile_x0, tile_y0);
+                if (live) {
+                    const uint32_t mask16 = subblock_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tile_x0, tile_y0);
+                    qmask = quadrant_bits(mask16);
+                    a.masks[range.x + start + e] = mask16;   // for the backward's staging (RenderFwdArgs::masks)
+                }
                 s_geo[e] = make_float4(xy.x, xy.y, (-0.5f * HSR_LOG2E) * co.x, -HSR_LOG2E * co.y);
                 s_co[e] = make_float2((-0.5f * HSR_LOG2E) * co.z, co.w);
             }

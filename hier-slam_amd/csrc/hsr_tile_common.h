@@ -189,12 +189,15 @@ __device__ __forceinline__ uint32_t subblock_mask(float x, float y, float cx, fl
 }
 
 // quadrant mask (bit q = wave q) from the exact sub-block test: a quadrant is visited iff one of its four sub-blocks is
+__device__ __forceinline__ uint32_t quadrant_bits(uint32_t mask)
+{
+    return (uint32_t)((mask & 0xFu) != 0u) | ((uint32_t)((mask & 0xF0u) != 0u) << 1) | ((uint32_t)((mask & 0xF00u) != 0u) << 2) |
+           ((uint32_t)((mask & 0xF000u) != 0u) << 3);
+}
 __device__ __forceinline__ uint32_t quadrant_mask_exact(float x, float y, float cx, float cy, float cz, float opacity, float tile_x0,
                                                         float tile_y0)
 {
-    const uint32_t mask = subblock_mask(x, y, cx, cy, cz, opacity, tile_x0, tile_y0);
-    return (uint32_t)((mask & 0xFu) != 0u) | ((uint32_t)((mask & 0xF0u) != 0u) << 1) | ((uint32_t)((mask & 0xF00u) != 0u) << 2) |
-           ((uint32_t)((mask & 0xF000u) != 0u) << 3);
+    return quadrant_bits(subblock_mask(x, y, cx, cy, cz, opacity, tile_x0, tile_y0));
 }
 
 constexpr int HSR_SUB_LSTRIDE = 260;   // bytes per sub-block list: 256 slots + 4 so that the four groups of a wave hit different banks
