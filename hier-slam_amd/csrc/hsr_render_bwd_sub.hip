@@ -387,12 +387,16 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 const float alpha = fminf(0.99f, co.y * G);
                 const bool active = valid && j >= j_first && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
 #ifdef HSR_TRACE
-                tr_iters++;
+                {   // (group, entry) visits, and those in which at least one of the group's 16 pixels accepts the splat
+                    const uint64_t bv = __ballot(valid), ba = __ballot(active);
+#pragma unroll
+                    for (int gg = 0; gg < 4; gg++) {
+                        tr_iters += ((bv >> (16 * gg)) & 0xFFFFull) != 0ull;
+                        tr_accepted += ((ba >> (16 * gg)) & 0xFFFFull) != 0ull;
+                    }
+                }
 #endif
                 if (__ballot(active) == 0ull) continue;
-#ifdef HSR_TRACE
-                tr_accepted++;
-#endif
 
                 const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
                 const float test_T = T * inv_one_m_a;

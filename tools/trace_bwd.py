@@ -45,13 +45,13 @@ a = a[a[:, 0] > 0]
 tot = a[:, 0].mean()
 print("kernel:", "render_bwd_sub_kernel" if sub else "render_bwd_mfma_kernel", " waves traced:", a.shape[0], "rc", rc)
 if sub:
-    names = ["total", "prologue", "stage+barriers", "loop(incl. flush)", "flush", "chunks", "iterations", "accepted"]
+    names = ["total", "prologue", "stage+barriers", "loop(incl. flush)", "flush", "chunks", "group visits", "... with a pixel that accepts"]
     for i, nm in enumerate(names):
         print("%-18s mean %10.0f   p10 %10.0f   p90 %10.0f   max %10.0f" % (nm, a[:, i].mean(), np.percentile(a[:, i], 10), np.percentile(a[:, i], 90), a[:, i].max()))
     print("fractions of wave time: prologue %.2f  stage %.2f  loop %.2f (of which flush + emission %.2f)" % (
         a[:, 1].mean() / tot, a[:, 2].mean() / tot, a[:, 3].mean() / tot, a[:, 4].mean() / tot))
-    print("cycles per iteration (loop excl. flush): %.0f ; flush + emission cycles per chunk: %.0f ; iterations per chunk: %.1f ; accepted %.2f" % (
-        (a[:, 3] - a[:, 4]).sum() / a[:, 6].sum(), a[:, 4].sum() / a[:, 5].sum(), a[:, 6].sum() / a[:, 5].sum(), a[:, 7].sum() / a[:, 6].sum()))
+    print("flush + emission cycles per chunk: %.0f ; (16-lane group, splat) visits per chunk: %.1f ; fraction of them in which a pixel accepts the splat: %.3f" % (
+        a[:, 4].sum() / a[:, 5].sum(), a[:, 6].sum() / a[:, 5].sum(), a[:, 7].sum() / a[:, 6].sum()))
 else:
     names = ["total", "prologue", "stage+barriers", "loop(no flush)", "flush", "emit", "visits", "accepted"]
     for i, nm in enumerate(names):
