@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     __shared__ int s_wmax[4];
     __shared__ float s_panel[4][SB_PANEL];
     __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
-    __shared__ uint32_t s_cid[4][SB_SLOTS];             // packed-row offset (Gaussian id x row stride) of each chunk row
+    __shared__ __attribute__((aligned(16))) uint32_t s_cid[4][SB_SLOTS];   // packed-row offset (Gaussian id x row stride) of each chunk row
     __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
@@ -254,14 +254,16 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
             for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Breg[g][m], acc[g], 0, 0, 0);
         }
         // D[row = 4*(lane>>4) + r][col = lane&15]: one atomic wave-instruction per register = 4 rows x 64 bytes
+        {
+            const uint4 b4 = *reinterpret_cast<const uint4*>(&s_cid[wv][4 * (lane >> 4)]);   // the four row offsets in one LDS read
+            const uint32_t bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            const int nr = nrows - 4 * (lane >> 4);   // how many of this lane's four rows exist
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 4 * (lane >> 4) + r;
-            const uint32_t base = s_cid[wv][row];
+            for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int g = 0; g < NG; g++)
-                if (row < nrows && colg[g] >= 0 && acc[g][r] != 0.f && !(a.debug_flags & 1))
-                    atomicAdd(a.grow + (base + (uint32_t)colg[g]), acc[g][r]);
+                for (int g = 0; g < NG; g++)
+                    if (r < nr && colg[g] >= 0 && acc[g][r] != 0.f && !(a.debug_flags & 1))
+                        atomicAdd(a.grow + (bb[r] + (uint32_t)colg[g]), acc[g][r]);
         }
         // butterfly columns 0..6: two wave-instructions of 8 rows x 7 values, so that each row's line is ONE request
 #pragma unroll
@@ -473,7 +475,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
     __shared__ uint8_t s_flat[4][256];
     __shared__ int s_wmax[4];
     __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
-    __shared__ uint32_t s_cid[4][SB_SLOTS];             // packed-row offset (Gaussian id x row stride) of each chunk row
+    __shared__ __attribute__((aligned(16))) uint32_t s_cid[4][SB_SLOTS];   // packed-row offset (Gaussian id x row stride) of each chunk row
     __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
@@ -696,7 +698,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
     __shared__ int s_wmax[4];
     __shared__ float s_panel[4][SB_PANEL];
     __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
-    __shared__ uint32_t s_cid[4][SB_SLOTS];             // packed-row offset (Gaussian id x row stride) of each chunk row
+    __shared__ __attribute__((aligned(16))) uint32_t s_cid[4][SB_SLOTS];   // packed-row offset (Gaussian id x row stride) of each chunk row
     __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
@@ -838,14 +840,16 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
             }
         }
         // D[row = 4*(lane>>4) + r][col = lane&15]: one atomic wave-instruction per register = 4 rows x 64 bytes
+        {
+            const uint4 b4 = *reinterpret_cast<const uint4*>(&s_cid[wv][4 * (lane >> 4)]);   // the four row offsets in one LDS read
+            const uint32_t bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            const int nr = nrows - 4 * (lane >> 4);   // how many of this lane's four rows exist
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 4 * (lane >> 4) + r;
-            const uint32_t base = s_cid[wv][row];
+            for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int g = 0; g < NG; g++)
-                if (row < nrows && colg[g] >= 0 && acc[g][r] != 0.f && !(a.debug_flags & 1))
-                    atomicAdd(a.grow + (base + (uint32_t)colg[g]), acc[g][r]);
+                for (int g = 0; g < NG; g++)
+                    if (r < nr && colg[g] >= 0 && acc[g][r] != 0.f && !(a.debug_flags & 1))
+                        atomicAdd(a.grow + (bb[r] + (uint32_t)colg[g]), acc[g][r]);
         }
         // butterfly columns 0..6: two wave-instructions of 8 rows x 7 values, so that each row's line is ONE request
 #pragma unroll
