@@ -128,11 +128,11 @@ struct FwdCfg {
 // are read for real — L2 hits — right before they are staged.  K = 74: 238 -> ~160 registers, i.e. three waves per SIMD instead of
 // two, in a kernel whose blend loop is bound by instruction issue.
 template <int KC, bool BASE, bool MASK, bool ALIGNED, bool SUB = false, bool PF = false>
-__global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ? 4 : 3) : 1)) render_fwd_kernel(RenderFwdArgs a, int c0)
+__global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ? 4 : (KC <= 80 ? 3 : 2)) : 1)) render_fwd_kernel(RenderFwdArgs a, int c0)
 {
     // SUB: 240 splats per batch keep the 16 lists + records of K = 26 under 40 KB (four workgroups per CU).  (PF at K = 26 with
     // 184-splat batches and five waves per SIMD was measured too: 96 registers with 5 spills, 0.174 vs 0.165 ms — not taken.)
-    constexpr int BATCH = (SUB && KC <= 32) ? (KC > 26 ? 200 : 240) : FwdCfg<KC>::BATCH;   // KC = 32: 200 x 176 B + lists < 40 KB
+    constexpr int BATCH = (SUB && KC <= 32) ? (KC > 26 ? 200 : 240) : ((PF && KC > 80) ? 128 : FwdCfg<KC>::BATCH);   // KC = 32: 200 x 176 B + lists < 40 KB; PF beyond 80 channels: two workgroups per CU, 128 x (32 + 4 KC + 8) B < 80 KB
     // per staged splat: a 32-byte record { x, y, A, B | C, opacity, r, g } (pre-scaled conic, see hsr_tile_common.h) — all the
     // alpha test needs, in two 16-byte reads at one address — and a feature row { s0 .. s(KC-1), b, depth } whose 16-byte reads
     // pair up with the packed FMAs (blue and depth ride in the row's padding at K = 26): one LDS read and one address
@@ -619,12 +619,18 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     // Gaussians: K = 32 0.41 -> see profiles/r02_fwd_generic_k.log); the matrix-core kernel keeps 81 <= K <= 124.
     // HSR_FWD_IMPL=wide restores its old range (parity-tested).
     static const bool prefer_wide = impl && !strcmp(impl, "wide");
-    const bool per_lane_pf = !force_valu && !prefer_wide && a.K >= 27 && a.K <= 80 && a.K != 74;
+    // Late round 2: with quad-shared rows the per-lane kernel also wins beyond 80 channels (tools/fwd_pf_max.sh, 500k Gaussians: K = 90
+    // 0.644 -> 0.557 ms, K = 102 0.712 -> 0.617, K = 124 0.732 -> 0.695) at two waves per SIMD: it takes every K in 27..128 now and the
+    // matrix-core forward is what HSR_FWD_IMPL=wide selects.
+    const bool per_lane_pf = !force_valu && !prefer_wide && a.K >= 27 && a.K <= 128 && a.K != 74;
     if (per_lane_pf) {
         if (a.K <= 32) render_fwd_kernel<32, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
         else if (a.K <= 48) render_fwd_kernel<48, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
         else if (a.K <= 64) render_fwd_kernel<64, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
-        else render_fwd_kernel<80, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
+        else if (a.K <= 80) render_fwd_kernel<80, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
+        else if (a.K <= 96) render_fwd_kernel<96, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
+        else if (a.K <= 112) render_fwd_kernel<112, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
+        else render_fwd_kernel<128, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;
     }
     if (!force_valu && a.K != 74 && hsr_launch_render_forward_wide(a, stream)) return HSR_OK;
