@@ -622,7 +622,9 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     // Late round 2: with quad-shared rows the per-lane kernel also wins beyond 80 channels (tools/fwd_pf_max.sh, 500k Gaussians: K = 90
     // 0.644 -> 0.557 ms, K = 102 0.712 -> 0.617, K = 124 0.732 -> 0.695) at two waves per SIMD: it takes every K in 27..128 now and the
     // matrix-core forward is what HSR_FWD_IMPL=wide selects.
-    const bool per_lane_pf = !force_valu && !prefer_wide && a.K >= 27 && a.K <= 128 && a.K != 74;
+    // (K = 74 and K = 102 — the reference's large ScanNet tree and its flat Replica label set — have instantiations of their exact width
+    // below: rows fetched as aligned float2, no padding channels: K = 74 0.371 vs 0.430 ms through the 80-channel kernel)
+    const bool per_lane_pf = !force_valu && !prefer_wide && a.K >= 27 && a.K <= 128 && a.K != 74 && a.K != 102;
     if (per_lane_pf) {
         if (a.K <= 32) render_fwd_kernel<32, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
         else if (a.K <= 48) render_fwd_kernel<48, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
@@ -633,7 +635,7 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
         else render_fwd_kernel<128, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;
     }
-    if (!force_valu && a.K != 74 && hsr_launch_render_forward_wide(a, stream)) return HSR_OK;
+    if (!force_valu && a.K != 74 && (a.K != 102 || prefer_wide) && hsr_launch_render_forward_wide(a, stream)) return HSR_OK;
     if (!force_valu) {
         switch (a.K) {
         case 0: render_fwd_kernel<0, true, false, false, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;
@@ -645,6 +647,12 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
             else render_fwd_kernel<74, true, false, true, true, true><<<grid, block, 0, stream>>>(a, 0);
             return HSR_OK;
         }
+        case 102:   // Replica flat label set
+            if (!prefer_wide) {
+                render_fwd_kernel<102, true, false, true, true, true><<<grid, block, 0, stream>>>(a, 0);
+                return HSR_OK;
+            }
+            break;
         default:
             if (a.K > 124 || a.K <= 28) {   // 32-channel chunks; the first chunk also produces the base outputs
                 render_fwd_kernel<32, true, false, false, true><<<grid, block, 0, stream>>>(a, 0);
