@@ -128,9 +128,10 @@ struct FwdCfg {
 // are read for real — L2 hits — right before they are staged.  K = 74: 238 -> ~160 registers, i.e. three waves per SIMD instead of
 // two, in a kernel whose blend loop is bound by instruction issue.
 template <int KC, bool BASE, bool MASK, bool ALIGNED, bool SUB = false, bool PF = false>
-__global__ void __launch_bounds__(256, (SUB && KC <= 26) ? 4 : (PF ? (KC <= 48 ? 4 : (KC <= 80 ? 3 : 2)) : 1)) render_fwd_kernel(RenderFwdArgs a, int c0)
+__global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : (PF ? (KC <= 48 ? 4 : (KC <= 80 ? 3 : 2)) : 1)) render_fwd_kernel(RenderFwdArgs a, int c0)
 {
-    // SUB: 240 splats per batch keep the 16 lists + records of K = 26 under 40 KB (four workgroups per CU).  (PF at K = 26 with
+    // SUB: 240 splats per batch keep the 16 lists + records of K = 26 under 40 KB (four workgroups per CU); K = 16 fits five (31 KB, 96
+    // registers: forward 0.147 -> 0.142 ms); K = 26 with touched rows + quad-shared rows at five: 0.177 vs 0.177 ms, not taken.  (PF at K = 26 with
     // 184-splat batches and five waves per SIMD was measured too: 96 registers with 5 spills, 0.174 vs 0.165 ms — not taken.)
     constexpr int BATCH = (SUB && KC <= 32) ? (KC > 26 ? 200 : 240) : ((PF && KC > 80) ? 128 : FwdCfg<KC>::BATCH);   // KC = 32: 200 x 176 B + lists < 40 KB; PF beyond 80 channels: two workgroups per CU, 128 x (32 + 4 KC + 8) B < 80 KB
     // per staged splat: a 32-byte record { x, y, A, B | C, opacity, r, g } (pre-scaled conic, see hsr_tile_common.h) — all the
