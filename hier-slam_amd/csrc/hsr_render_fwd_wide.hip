@@ -1,3 +1,5 @@
+// (Since late round 2 the per-lane kernel of hsr_render_fwd.hip — sub-block lists, rows touched into L2, quad-shared row reads — is faster at
+// every width: this kernel runs only under HSR_FWD_IMPL=wide, as a parity-tested second implementation.)
 // hsr_render_fwd_wide.hip — forward tile kernel for WIDE semantic trees (29 <= K <= 124: the reference's 74- and
 // 102-channel configurations, config.h:18), blend accumulation on the matrix cores.
 //
