@@ -124,6 +124,12 @@ def parity_block(cam_cpu, sc, up, oracle_first, dev):
     ok_int = all(rep[k] for k in ("num_rendered_equal", "radii_equal", "tiles_touched_equal", "keys_equal", "vals_equal", "ranges_equal"))
     rep["pass"] = bool(ok_int and max(rep["grad_err_over_max"].values()) <= 1e-4 and max(rep["image_err_over_max"].values()) <= 1e-4
                        and max(rep["grad_elementwise_err"].values()) <= 1e-4)
+    # "pass" is strict on purpose.  A threshold decision taken the other way (alpha >= 1/255 within an ulp: v_exp_f32 vs glibc) moves a
+    # pixel by a whole contribution and is likely somewhere in 2M pixels x hundreds of splats: the oracle flags the pixels / splats at
+    # risk, and pass_outside_tie_risk says whether everything else is within the bound
+    rep["pass_outside_tie_risk"] = bool(ok_int and max(rep["grad_err_over_max_outside_tie_risk"].values()) <= 1e-4
+                                        and max(rep["image_err_over_max_outside_tie_risk"].values()) <= 1e-4
+                                        and max(rep["grad_elementwise_err_outside_tie_risk"].values()) <= 1e-4)
     st_o.free()
     return rep
 

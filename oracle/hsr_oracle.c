@@ -259,7 +259,15 @@ typedef struct HsroState {
     float* final_T;         /* [N]                                        (ImageState.accum_alpha)      */
     uint32_t* n_contrib;    /* [N]                                        (ImageState.n_contrib)        */
     uint32_t* median_pos;   /* [N] 1 + list position of the splat at which T crossed 0.5 (0: never); not in the reference */
+    /* Test aid, not in the reference: where a comparison with ANOTHER fp32 implementation of this loop may legitimately differ by a whole
+     * contribution.  The loop takes hard decisions on computed floats — power > 0, alpha >= 1/255, T(1-alpha) < 1e-4, T crossing 0.5 — and
+     * expf / exp2 implementations differ in the last ulps.  tie_pixels[pix] != 0: some decision of that pixel was taken within HSRO_TIE_EPS
+     * (relative) of its threshold; tie_gaussians[id] != 0: the splat contributes to such a pixel (its gradient rows see the difference). */
+    uint8_t* tie_pixels;    /* [N] */
+    uint8_t* tie_gaussians; /* [P] */
 } HsroState;
+
+#define HSRO_TIE_EPS 2e-6f   /* a few ulps of alpha; T drifts by less over a tile's list (same fp32 products, alpha differing in the last ulp) */
 
 static int g_median_rule = 0;
 static long g_median_disagree = 0;
@@ -272,7 +280,7 @@ void hsro_free(HsroState* s)
     free(s->depths); free(s->means2D); free(s->conic_opacity); free(s->cov3D); free(s->rgb); free(s->clamped);
     free(s->radii); free(s->tiles_touched); free(s->point_offsets); free(s->keys_unsorted); free(s->keys);
     free(s->vals_unsorted); free(s->vals); free(s->ranges); free(s->final_T); free(s->n_contrib);
-    free(s->median_pos);
+    free(s->median_pos); free(s->tie_pixels); free(s->tie_gaussians);
     free(s);
 }
 
@@ -285,7 +293,8 @@ const void* hsro_field(const HsroState* s, int id)
     case 4: return s->rgb; case 5: return s->clamped; case 6: return s->radii; case 7: return s->tiles_touched;
     case 8: return s->point_offsets; case 9: return s->keys_unsorted; case 10: return s->keys;
     case 11: return s->vals_unsorted; case 12: return s->vals; case 13: return s->ranges; case 14: return s->final_T;
-    case 15: return s->n_contrib; case 16: return s->median_pos; default: return 0;
+    case 15: return s->n_contrib; case 16: return s->median_pos; case 17: return s->tie_pixels; case 18: return s->tie_gaussians;
+    default: return 0;
     }
 }
 
@@ -342,6 +351,7 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
     s->radii = (int*)calloc(Pa, 4); s->tiles_touched = (uint32_t*)calloc(Pa, 4); s->point_offsets = (uint32_t*)calloc(Pa, 4);
     s->ranges = (uint32_t*)calloc(Tn * 2, 4); s->final_T = (float*)calloc(N, 4); s->n_contrib = (uint32_t*)calloc(N, 4);
     s->median_pos = (uint32_t*)calloc(N, 4);
+    s->tie_pixels = (uint8_t*)calloc(N, 1); s->tie_gaussians = (uint8_t*)calloc(Pa, 1);
     s->has_sh = colors_precomp == 0; s->own_cov3d = cov3D_precomp == 0;
 
     /* rasterizer_impl.cu:226-227 */
@@ -451,17 +461,22 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
                 float C[NUM_CHANNELS] = {0, 0, 0}; float Dd = 0; float median_D = 15.0f; float Mm = 0;
                 uint32_t median_at = 0;
                 for (int ch = 0; ch < K; ch++) Sacc[ch] = 0;
+                int risk = 0; uint32_t i_end = r1;   /* test aid (tie_pixels): decisions taken within HSRO_TIE_EPS of their threshold */
                 for (uint32_t i = r0; i < r1; i++) {
                     contributor++;
                     uint32_t id = s->vals[i];
                     float dx = s->means2D[2 * id] - pfx, dy = s->means2D[2 * id + 1] - pfy;
                     const float* co = s->conic_opacity + 4 * (size_t)id;
                     float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (fabsf(power) <= 1e-6f && co[3] >= 1.0f / 255.0f) risk = 1;
                     if (power > 0.0f) continue;
                     float alpha = fminf_(0.99f, co[3] * expf(power));
+                    if (fabsf(alpha - 1.0f / 255.0f) <= HSRO_TIE_EPS * (1.0f / 255.0f)) risk = 1;
                     if (alpha < 1.0f / 255.0f) continue;
                     float test_T = T * (1 - alpha);
-                    if (test_T < 0.0001f) break; /* done = true (forward.cu:358-362, :496-500) */
+                    if (fabsf(test_T - 0.0001f) <= 4.0f * HSRO_TIE_EPS * 0.0001f) risk = 1;
+                    if (fabsf(T - 0.5f) <= 4.0f * HSRO_TIE_EPS * 0.5f || fabsf(test_T - 0.5f) <= 4.0f * HSRO_TIE_EPS * 0.5f) risk = 1;
+                    if (test_T < 0.0001f) { i_end = i + 1; break; } /* done = true (forward.cu:358-362, :496-500) */
                     for (int ch = 0; ch < NUM_CHANNELS; ch++) C[ch] += feat[(size_t)id * NUM_CHANNELS + ch] * alpha * T;
                     Dd += s->depths[id] * alpha * T;
                     if (s->semantic) { for (int ch = 0; ch < K; ch++) Sacc[ch] += semantics[(size_t)id * K + ch] * alpha * T; }
@@ -471,6 +486,17 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
                     last_contributor = contributor;
                 }
                 s->final_T[pix_id] = T; s->n_contrib[pix_id] = last_contributor; s->median_pos[pix_id] = median_at;
+                if (risk) {   /* every splat that reaches (or nearly reaches) alpha >= 1/255 on this pixel sees the difference */
+                    s->tie_pixels[pix_id] = 1;
+                    for (uint32_t i = r0; i < i_end; i++) {
+                        uint32_t id = s->vals[i];
+                        float dx = s->means2D[2 * id] - pfx, dy = s->means2D[2 * id + 1] - pfy;
+                        const float* co = s->conic_opacity + 4 * (size_t)id;
+                        float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 1e-6f) continue;
+                        if (fminf_(0.99f, co[3] * expf(power)) >= (1.0f / 255.0f) * (1.0f - HSRO_TIE_EPS)) s->tie_gaussians[id] = 1;   /* benign race: all writers store 1 */
+                    }
+                }
                 for (int ch = 0; ch < NUM_CHANNELS; ch++) out_color[(size_t)ch * N + pix_id] = C[ch];
                 out_depth[pix_id] = Dd; out_median_depth[pix_id] = median_D; out_opacity[pix_id] = 1 - T;
                 if (s->semantic) { for (int ch = 0; ch < K; ch++) out_semantic[(size_t)ch * N + pix_id] = Sacc[ch]; }

@@ -52,6 +52,13 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         w = worst[name]
         tr.write_line("%-28s n=%-4d err/max %.2e   element-wise at floor 1/0.1/0.01/0.001: %s" % (
             name, w["cases"], w["err_over_max"], " ".join("%.1e" % w["elementwise"].get(f, 0.0) for f in ("1", "0.1", "0.01", "0.001"))))
+    try:
+        import test_gpu_parity
+        if test_gpu_parity.TIE_MASKED:
+            tr.write_line("comparisons that passed only OUTSIDE the oracle's tie-risk pixels / splats (threshold decisions within ulps): %d (%s)" % (
+                len(test_gpu_parity.TIE_MASKED), ", ".join(sorted(set(test_gpu_parity.TIE_MASKED)))))
+    except Exception:
+        pass
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         import json

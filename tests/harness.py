@@ -200,6 +200,21 @@ def parity_report(out_g, gr_g, st_g, out_o, gr_o, st_o, semantic=True):
     md = np.abs(out_g["median_depth"] - out_o["median_depth"])
     img["median_depth_excluding_outliers"] = float(md[md <= 1e-4].max()) if (md <= 1e-4).any() else 0.0
     rep["image_max_abs_err"], rep["image_err_over_max"] = img, img_rel
+    # A pixel whose contributor count (or crossing splat) differs took a threshold decision the other way — alpha >= 1/255, T < 1e-4 or
+    # T < 0.5 within an ulp, v_exp_f32 here vs glibc in the oracle — and differs by that splat's whole contribution; at 2M pixels x
+    # hundreds of splats such a tie is likely.  Reported: how many, and the image errors over all OTHER pixels.
+    # The oracle flags the pixels in which one of those decisions fell within a few ulps of its threshold, and the splats that contribute to
+    # them (oracle/hsr_oracle.c: tie_pixels, tie_gaussians).
+    tie = np.asarray(f("tie_pixels")).astype(bool).reshape(-1)
+    tie_g = np.asarray(f("tie_gaussians")).astype(bool).reshape(-1)
+    rep["oracle_tie_risk_pixels"], rep["oracle_tie_risk_gaussians"] = int(tie.sum()), int(tie_g.sum())
+    excl = {}
+    for n in ["color", "depth", "opacity"] + (["semantic"] if semantic else ["mask"]):
+        g_ = np.asarray(out_g[n], np.float64).reshape(-1, npix)
+        o_ = np.asarray(out_o[n], np.float64).reshape(-1, npix)
+        keep = ~tie
+        excl[n] = float(np.abs(g_[:, keep] - o_[:, keep]).max() / max(np.abs(o_).max(), 1e-30)) if keep.any() else 0.0
+    rep["image_err_over_max_outside_tie_risk"] = excl
     ga, gr, ge = {}, {}, {}
     for n in gr_o:
         s = error_stats(gr_g[n], gr_o[n])
@@ -210,5 +225,25 @@ def parity_report(out_g, gr_g, st_g, out_o, gr_o, st_o, semantic=True):
     rep["grad_max_abs_err"], rep["grad_err_over_max"] = ga, gr
     rep["grad_elementwise_err"] = ge
     rep["grad_elementwise_floor"] = {n: floor_for(n) for n in gr_o}
+    # how many gradient ELEMENTS sit outside the element-wise bound (a tie pixel moves the rows of the few Gaussians it involves)
+    rep["grad_elements_outside_bound"] = {
+        n: int((np.abs(np.asarray(gr_g[n], np.float64) - np.asarray(gr_o[n], np.float64).reshape(np.asarray(gr_g[n]).shape))
+                > 1e-4 * np.maximum(np.abs(np.asarray(gr_o[n], np.float64).reshape(np.asarray(gr_g[n]).shape)),
+                                    floor_for(n) * max(float(np.abs(gr_o[n]).max()) if np.asarray(gr_o[n]).size else 0.0, 1e-30))).sum())
+        for n in gr_o}
     rep["grad_max_abs"] = {n: float(np.abs(gr_o[n]).max()) if np.asarray(gr_o[n]).size else 0.0 for n in gr_o}
+    go_, ge_ = {}, {}
+    for n in gr_o:
+        got = np.asarray(gr_g[n], np.float64)
+        exp = np.asarray(gr_o[n], np.float64).reshape(got.shape)
+        if got.size == 0 or got.shape[0] != tie_g.size:
+            go_[n], ge_[n] = rep["grad_err_over_max"][n], rep["grad_elementwise_err"][n]
+            continue
+        keep = ~tie_g
+        mx = max(float(np.abs(exp).max()), 1e-30)
+        d = np.abs(got - exp).reshape(tie_g.size, -1)[keep]
+        e = np.abs(exp).reshape(tie_g.size, -1)[keep]
+        go_[n] = float(d.max() / mx) if d.size else 0.0
+        ge_[n] = float((d / np.maximum(e, floor_for(n) * mx)).max()) if d.size else 0.0
+    rep["grad_err_over_max_outside_tie_risk"], rep["grad_elementwise_err_outside_tie_risk"] = go_, ge_
     return rep

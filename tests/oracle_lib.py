@@ -14,7 +14,7 @@ _lib = None
 
 FIELDS = dict(depths=0, means2D=1, conic_opacity=2, cov3D=3, rgb=4, clamped=5, radii=6, tiles_touched=7,
               point_offsets=8, keys_unsorted=9, keys=10, vals_unsorted=11, vals=12, ranges=13, final_T=14, n_contrib=15,
-              median_pos=16)
+              median_pos=16, tie_pixels=17, tie_gaussians=18)
 
 
 def build(force=False):
@@ -74,7 +74,8 @@ class OracleState:
                     radii=(np.int32, (P,)), tiles_touched=(np.uint32, (P,)), point_offsets=(np.uint32, (P,)),
                     keys_unsorted=(np.uint64, (R,)), keys=(np.uint64, (R,)), vals_unsorted=(np.uint32, (R,)),
                     vals=(np.uint32, (R,)), ranges=(np.uint32, (T, 2)), final_T=(np.float32, (N,)),
-                    n_contrib=(np.uint32, (N,)), median_pos=(np.uint32, (N,)))[name]
+                    n_contrib=(np.uint32, (N,)), median_pos=(np.uint32, (N,)), tie_pixels=(np.uint8, (N,)),
+                    tie_gaussians=(np.uint8, (P,)))[name]
         n = int(np.prod(spec[1]))
         if n == 0:
             return np.zeros(spec[1], dtype=spec[0])
