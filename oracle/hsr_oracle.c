@@ -468,10 +468,14 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
                     float dx = s->means2D[2 * id] - pfx, dy = s->means2D[2 * id + 1] - pfy;
                     const float* co = s->conic_opacity + 4 * (size_t)id;
                     float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (fabsf(power) <= 1e-6f && co[3] >= 1.0f / 255.0f) risk = 1;
+                    /* how far two correct fp32 evaluations of `power` can be apart: a few roundings of its three terms (the reference's
+                     * own nvcc build contracts them into FMAs; the HIP path evaluates a pre-scaled form) — relative to alpha that is an
+                     * ABSOLUTE difference in power, which for elongated splats (large cancelling terms) is far more than an ulp of alpha */
+                    const float pw_slack = 4.0f * 5.96e-8f * (0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy));
+                    if (fabsf(power) <= 1e-6f + pw_slack && co[3] >= 1.0f / 255.0f) risk = 1;
                     if (power > 0.0f) continue;
                     float alpha = fminf_(0.99f, co[3] * expf(power));
-                    if (fabsf(alpha - 1.0f / 255.0f) <= HSRO_TIE_EPS * (1.0f / 255.0f)) risk = 1;
+                    if (fabsf(alpha - 1.0f / 255.0f) <= (HSRO_TIE_EPS + pw_slack) * (1.0f / 255.0f)) risk = 1;
                     if (alpha < 1.0f / 255.0f) continue;
                     float test_T = T * (1 - alpha);
                     if (fabsf(test_T - 0.0001f) <= 4.0f * HSRO_TIE_EPS * 0.0001f) risk = 1;
@@ -493,8 +497,9 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
                         float dx = s->means2D[2 * id] - pfx, dy = s->means2D[2 * id + 1] - pfy;
                         const float* co = s->conic_opacity + 4 * (size_t)id;
                         float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                        if (power > 1e-6f) continue;
-                        if (fminf_(0.99f, co[3] * expf(power)) >= (1.0f / 255.0f) * (1.0f - HSRO_TIE_EPS)) s->tie_gaussians[id] = 1;   /* benign race: all writers store 1 */
+                        const float pw_slack = 4.0f * 5.96e-8f * (0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy));
+                        if (power > 1e-6f + pw_slack) continue;
+                        if (fminf_(0.99f, co[3] * expf(power)) >= (1.0f / 255.0f) * (1.0f - HSRO_TIE_EPS - pw_slack)) s->tie_gaussians[id] = 1;   /* benign race: all writers store 1 */
                     }
                 }
                 for (int ch = 0; ch < NUM_CHANNELS; ch++) out_color[(size_t)ch * N + pix_id] = C[ch];

@@ -213,7 +213,7 @@ def parity_report(out_g, gr_g, st_g, out_o, gr_o, st_o, semantic=True):
         g_ = np.asarray(out_g[n], np.float64).reshape(-1, npix)
         o_ = np.asarray(out_o[n], np.float64).reshape(-1, npix)
         keep = ~tie
-        excl[n] = float(np.abs(g_[:, keep] - o_[:, keep]).max() / max(np.abs(o_).max(), 1e-30)) if keep.any() else 0.0
+        excl[n] = float(np.abs(g_[:, keep] - o_[:, keep]).max() / max(np.abs(o_).max(), 1e-30)) if (keep.any() and g_.size) else 0.0
     rep["image_err_over_max_outside_tie_risk"] = excl
     ga, gr, ge = {}, {}, {}
     for n in gr_o:
