@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """profiles/<name>.json (tools/summarize_profile.py) -> profiles/traffic_latest.json: the PMC-derived HBM traffic per launch
 that bench.py attaches to its roofline object, plus — per tile kernel — what the same counters say bounds it (`limiter`).
-usage: python tools/make_traffic_json.py profiles/r02_g_final.json [P W H K kind]"""
+usage: python tools/make_traffic_json.py profiles/r02_h_final.json [P W H K kind]"""
 import json
 import os
 import sys
