@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     __shared__ float s_panel[4][SB_PANEL];
     __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
     __shared__ __attribute__((aligned(16))) uint32_t s_cid[4][SB_SLOTS];   // packed-row offset (Gaussian id x row stride) of each chunk row
-    __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
+    __shared__ __attribute__((aligned(16))) float s_u7[4][SB_SLOTS * 8 * 4];   // [row][value 0..7][group]: butterfly sums; the four groups of a value are ONE 16-byte read at emission
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
     if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
@@ -276,10 +276,10 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
             const float4 gj = s_ent[3 * ja];
             const float cxj = s_ent[3 * ja + 2].x;
             const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
-            const float* sa = u7 + row * 32 + ca;
-            const float* sb = u7 + row * 32 + cb;
-            const float ta = (sa[0] + sa[8]) + (sa[16] + sa[24]);
-            const float tb = (sb[0] + sb[8]) + (sb[16] + sb[24]);
+            const float4 sa = *reinterpret_cast<const float4*>(u7 + row * 32 + ca * 4);
+            const float4 sb = *reinterpret_cast<const float4*>(u7 + row * 32 + cb * 4);
+            const float ta = (sa.x + sa.y) + (sa.z + sa.w);
+            const float tb = (sb.x + sb.y) + (sb.z + sb.w);
             const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
             const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
             const float val = fmaf(wb, tb, wa * ta);
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                     T = test_T;
                 }
                 const float total7 = row_reduce_transpose7(v, lane);
-                if (myv_on && valid) u7[r * 32 + gq * 8 + myv] = total7;
+                if (myv_on && valid) u7[r * 32 + myv * 4 + gq] = total7;
             }
             {
                 const long long tf = TR_NOW();
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
     __shared__ int s_wmax[4];
     __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
     __shared__ __attribute__((aligned(16))) uint32_t s_cid[4][SB_SLOTS];   // packed-row offset (Gaussian id x row stride) of each chunk row
-    __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
+    __shared__ __attribute__((aligned(16))) float s_u7[4][SB_SLOTS * 8 * 4];   // [row][value 0..7][group]: butterfly sums; the four groups of a value are ONE 16-byte read at emission
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
     if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
@@ -535,10 +535,10 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
             const float4 gj = s_ent[3 * ja];
             const float cxj = s_ent[3 * ja + 2].x;
             const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
-            const float* sa = u7 + row * 32 + ca;
-            const float* sb = u7 + row * 32 + cb;
-            const float ta = (sa[0] + sa[8]) + (sa[16] + sa[24]);
-            const float tb = (sb[0] + sb[8]) + (sb[16] + sb[24]);
+            const float4 sa = *reinterpret_cast<const float4*>(u7 + row * 32 + ca * 4);
+            const float4 sb = *reinterpret_cast<const float4*>(u7 + row * 32 + cb * 4);
+            const float ta = (sa.x + sa.y) + (sa.z + sa.w);
+            const float tb = (sb.x + sb.y) + (sb.z + sb.w);
             const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
             const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
             const float val = fmaf(wb, tb, wa * ta);
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                     T = test_T;
                 }
                 const float total7 = row_reduce_transpose7(v, lane);
-                if (myv_on && valid) u7[r * 32 + gq * 8 + myv] = total7;
+                if (myv_on && valid) u7[r * 32 + myv * 4 + gq] = total7;
             }
             if (c0 == 0) HSR_SETTLE_STAGING();
             flush(nrows);
@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
     __shared__ float s_panel[4][SB_PANEL];
     __shared__ uint8_t s_cj[4][SB_SLOTS];               // batch slot of each chunk row
     __shared__ __attribute__((aligned(16))) uint32_t s_cid[4][SB_SLOTS];   // packed-row offset (Gaussian id x row stride) of each chunk row
-    __shared__ float s_u7[4][SB_SLOTS * 4 * 8];         // [row][group][8]: butterfly sums of one group for one chunk row
+    __shared__ __attribute__((aligned(16))) float s_u7[4][SB_SLOTS * 8 * 4];   // [row][value 0..7][group]: butterfly sums; the four groups of a value are ONE 16-byte read at emission
 
     const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
     if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
@@ -859,10 +859,10 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
             const float4 gj = s_ent[3 * ja];
             const float cxj = s_ent[3 * ja + 2].x;
             const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
-            const float* sa = u7 + row * 32 + ca;
-            const float* sb = u7 + row * 32 + cb;
-            const float ta = (sa[0] + sa[8]) + (sa[16] + sa[24]);
-            const float tb = (sb[0] + sb[8]) + (sb[16] + sb[24]);
+            const float4 sa = *reinterpret_cast<const float4*>(u7 + row * 32 + ca * 4);
+            const float4 sb = *reinterpret_cast<const float4*>(u7 + row * 32 + cb * 4);
+            const float ta = (sa.x + sa.y) + (sa.z + sa.w);
+            const float tb = (sb.x + sb.y) + (sb.z + sb.w);
             const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
             const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
             const float val = fmaf(wb, tb, wa * ta);
@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
                     T = test_T;
                 }
                 const float total7 = row_reduce_transpose7(v, lane);
-                if (myv_on && valid) u7[r * 32 + gq * 8 + myv] = total7;
+                if (myv_on && valid) u7[r * 32 + myv * 4 + gq] = total7;
             }
             if (c0 == 0) HSR_SETTLE_STAGING();
             flush(nrows);
