@@ -147,7 +147,7 @@ backward_common(bool semantic, const OptT& background, const at::Tensor& means3D
                 const OptT& dL_dout_semantic, const at::Tensor& dL_dout_depth, const at::Tensor& dL_dout_median_depth,
                 const at::Tensor& dL_dout_final_opacity, const OptT& sh, int64_t degree, const OptT& campos,
                 const at::Tensor& geomBuffer, int64_t R, const at::Tensor& binningBuffer, const at::Tensor& imageBuffer, bool debug,
-                bool want_cov3D_grad, bool geometry_only, int64_t stream)
+                bool want_cov3D_grad, bool geometry_only, int64_t stream, const c10::optional<std::vector<OptT>>& sunk)
 {
     TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization: tensors must live on a HIP device (got ", means3D.device(),
                 "); this build has no CPU path");
@@ -163,11 +163,17 @@ backward_common(bool semantic, const OptT& background, const at::Tensor& means3D
     const size_t nscratch = P ? hsr_backward_scratch_bytes((int)P, (int)K, (int)R) : 0;
     // geometry-only (tracking iteration): no gradient wanted for colours, opacities, semantics, scales, rotations, SH, cov3D
     const bool geo = geometry_only && nscratch && hsr_get_backward_mode() == 0 && colors.has_value() && colors->defined() && colors->numel() != 0;
-    at::Tensor dL_dmeans3D = fresh({P, 3}), dL_dmeans2D = fresh({P, 3});
+    // gradient sink (diff_gaussian_rasterization/_C.py set_gradient_sink): pre-allocated outputs — views of a communication
+    // bucket — for means3D, colours, semantics, opacities, scales, rotations (checked for shape / dtype / device / layout there)
+    auto take = [&](size_t i, at::IntArrayRef shape) {
+        if (sunk.has_value() && i < sunk->size() && (*sunk)[i].has_value() && (*sunk)[i]->defined()) return *(*sunk)[i];
+        return fresh(shape);
+    };
+    at::Tensor dL_dmeans3D = take(0, {P, 3}), dL_dmeans2D = fresh({P, 3});
     at::Tensor dL_dcolors, dL_dsemantics, dL_dopacity, dL_dsh, dL_dscales, dL_drotations;
     if (!geo) {
-        dL_dcolors = fresh({P, NUM_CHANNELS}); dL_dsemantics = fresh({P, K}); dL_dopacity = fresh({P, 1}); dL_dsh = fresh({P, M, 3});
-        dL_dscales = fresh({P, 3}); dL_drotations = fresh({P, 4});
+        dL_dcolors = take(1, {P, NUM_CHANNELS}); dL_dsemantics = take(2, {P, K}); dL_dopacity = take(3, {P, 1}); dL_dsh = fresh({P, M, 3});
+        dL_dscales = take(4, {P, 3}); dL_drotations = take(5, {P, 4});
     }
     at::Tensor dL_dconic, dL_ddepths, dL_dcov3D, scratch;
     if (!nscratch) { dL_dconic = fresh({P, 2, 2}); dL_ddepths = fresh({P, 1}); }

@@ -149,6 +149,32 @@ class _HintMap(dict):
 
 _binning_hint = _HintMap()
 
+# Gradient sink (hsr_utils/parallel.py GradientExchange): a callable (name, shape, device) -> tensor | None that may hand the
+# backward a PRE-ALLOCATED output tensor — a fresh view of a communication bucket — for a named gradient, so that the
+# gradient is written where the all-reduce will read it and nothing is copied afterwards.  Names: "raster.means3D",
+# "raster.colors_precomp", "raster.semantics_precomp", "raster.opacities", "raster.scales", "raster.rotations" here;
+# "params.means3D", "params.unnorm_rotations", "params.logit_opacities", "params.log_scales" in hsr_utils/slam_helpers.py.
+# None (default): every gradient is a fresh allocation, as in the reference (rasterize_points.cu:378-388).
+_gradient_sink = None
+
+
+def set_gradient_sink(fn):
+    """install (or, with None, remove) the gradient sink; returns the previous one"""
+    global _gradient_sink
+    prev, _gradient_sink = _gradient_sink, fn
+    return prev
+
+
+def _from_sink(name, shape, dev):
+    if _gradient_sink is None:
+        return None
+    t = _gradient_sink(name, tuple(int(x) for x in shape), dev)
+    if t is None:
+        return None
+    if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+        raise RuntimeError("gradient sink returned a tensor of the wrong shape / dtype / device / layout for %s" % name)
+    return t
+
 def _rows_or_legacy():
     return int(_lib.hsr_get_backward_mode()) != 0
 
@@ -307,13 +333,19 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic,
                      dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
                      binningBuffer, imageBuffer, debug, want_cov3D_grad=True, geometry_only=False):
+    sunk = None
+    if _gradient_sink is not None and means3D.is_cuda and int(means3D.size(0)) != 0:
+        P_, K_ = int(means3D.size(0)), (int(dL_dout_semantic.size(0)) if semantic else 0)
+        sunk = [_from_sink("raster." + n, shp, means3D.device) for n, shp in (
+            ("means3D", (P_, 3)), ("colors_precomp", (P_, NUM_CHANNELS)), ("semantics_precomp", (P_, K_)), ("opacities", (P_, 1)),
+            ("scales", (P_, 3)), ("rotations", (P_, 4)))]
     if _ext is not None and means3D.is_cuda:
         return _ext.backward_common(bool(semantic), background, means3D, radii, colors, semantics, scales, rotations,
                                     float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
                                     dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity,
                                     sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug),
                                     bool(want_cov3D_grad), bool(geometry_only),
-                                    torch.cuda.current_stream(means3D.device).cuda_stream)
+                                    torch.cuda.current_stream(means3D.device).cuda_stream, sunk)
     _require_gpu(means3D)
     dev = means3D.device
     P = int(means3D.size(0))
@@ -324,21 +356,23 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
     new = torch.zeros if P == 0 else torch.empty  # the library overwrites every element when P > 0
     packed_ok = P != 0 and int(_lib.hsr_backward_scratch_bytes(P, K, int(R))) > 0 and int(_lib.hsr_backward_scratch_bytes(P, K, 0)) > 0
     geo = bool(geometry_only) and packed_ok and colors is not None and colors.numel() != 0 and not _rows_or_legacy()
-    dL_dmeans3D = new((P, 3), **fopt)
+    pre = (lambda i: sunk[i] if (sunk is not None and sunk[i] is not None) else None)
+    take = (lambda i, shape: pre(i) if pre(i) is not None else new(shape, **fopt))
+    dL_dmeans3D = take(0, (P, 3))
     dL_dmeans2D = new((P, 3), **fopt)
-    dL_dcolors = None if geo else new((P, NUM_CHANNELS), **fopt)
-    dL_dsemantics = None if geo else new((P, K), **fopt)
+    dL_dcolors = None if geo else take(1, (P, NUM_CHANNELS))
+    dL_dsemantics = None if geo else take(2, (P, K))
     # with a scratch buffer (every mode but 'legacy') dL_dconic and dL_ddepths are intermediates nobody reads (the reference
     # keeps them inside RasterizeGaussiansBackwardCUDA, rasterize_points.cu:380-383): not allocated, not written;
     # dL_dcov3D only when the caller wants it (want_cov3D_grad=False from the autograd node when cov3D_precomp needs no grad)
     packed_scratch = P != 0 and int(_lib.hsr_backward_scratch_bytes(P, K, int(R))) > 0
     dL_dconic = None if packed_scratch else new((P, 2, 2), **fopt)
     dL_ddepths = None if packed_scratch else new((P, 1), **fopt)
-    dL_dopacity = None if geo else new((P, 1), **fopt)
+    dL_dopacity = None if geo else take(3, (P, 1))
     dL_dcov3D = new((P, 6), **fopt) if ((want_cov3D_grad and not geo) or P == 0) else None
     dL_dsh = None if geo else new((P, M, 3), **fopt)
-    dL_dscales = None if geo else new((P, 3), **fopt)
-    dL_drotations = None if geo else new((P, 4), **fopt)
+    dL_dscales = None if geo else take(4, (P, 3))
+    dL_drotations = None if geo else take(5, (P, 4))
     if P != 0:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream

@@ -116,3 +116,191 @@ def allreduce_gradients(params, group=None, average=False, bucket=None):
 def shard_keyframes(keyframe_ids, rank, world_size):
     """Round-robin assignment of the mapping window's keyframes to ranks: rank r renders ids[r::world]."""
     return list(keyframe_ids)[rank::world_size]
+
+
+class GradientExchange:
+    """The exchange step of the keyframe-parallel mapping path with nothing copied and nothing exchanged that no rank produced.
+
+    * **Zero copy.**  `params` maps gradient-sink names ("raster.means3D", "raster.colors_precomp", ... for tensors fed straight
+      to the rasterizer; "params.means3D", "params.log_scales", ... for the fused input preparation of hsr_utils.slam_helpers:
+      diff_gaussian_rasterization/_C.py set_gradient_sink) to the leaf tensors.  begin_step() clears their `.grad` and installs a
+      sink that hands the backward fresh VIEWS of the current bucket as its gradient outputs; autograd's AccumulateGrad adopts an
+      incoming gradient nobody else references instead of copying it, so after backward() every `leaf.grad` IS a slice of the
+      bucket and submit() starts the all-reduce on the bucket as it stands.  (A leaf whose gradient did not come from the sink —
+      another producer, an accumulated second backward — is copied into its slot like GradientBucket.pack; stats() counts both.)
+    * **Visibility-sparse.**  A keyframe sees part of the map: rows of Gaussians with radii <= 0 on EVERY rank are exact zeros on
+      every rank.  announce(radii) — called by begin_step when it is given the forward's radii — all-reduces (max) the byte mask
+      radii > 0 on a side stream while the backward runs; submit() then exchanges only the rows of the union: gather into a
+      compact buffer, ONE all-reduce, scatter back.  The result equals the dense all-reduce — bit for bit with two ranks (a + b),
+      up to the order of the ring's fp32 additions with more — and rows outside the union stay the zeros the backward wrote.
+      When the union covers more than `dense_above` of the rows the bucket is all-reduced whole (no gather / scatter).
+    * **Pipelined** like PipelinedAllReduce: `depth` buckets, a bucket is waited for only when it is handed out again, drain()
+      at the end; reduced(step) gives the summed gradients of a step as views.
+    """
+
+    def __init__(self, params, device, depth=2, group=None, average=False, sparse=True, dense_above=0.75):
+        if not isinstance(params, dict):
+            raise TypeError("params: {gradient-sink name: leaf tensor}")
+        self.names = list(params)
+        self.leaves = [params[n] for n in self.names]
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.P = int(self.leaves[0].shape[0])
+        for t in self.leaves:
+            if t.dim() < 1 or int(t.shape[0]) != self.P:
+                raise ValueError("every exchanged tensor needs one row per Gaussian")
+        self.buckets = [GradientBucket([t.shape for t in self.leaves], device) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.group, self.average, self.sparse, self.dense_above = group, average, bool(sparse), float(dense_above)
+        self.step, self.cur = 0, None
+        self._mask = None          # (pending work | None, uint8 [P] union mask, event | None)
+        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self._handed = {}
+        self._stats = dict(steps=0, zero_copy_tensors=0, copied_tensors=0, bytes_dense_equivalent=0, bytes_exchanged=0,
+                           sparse_steps=0, union_rows=0, mask_bytes=0)
+
+    # ---- the sink ----
+    def _sink(self, name, shape, dev):
+        if self.cur is None or name not in self.names:
+            return None
+        i = self.names.index(name)
+        b = self.buckets[self.cur]
+        if tuple(shape) != b.shapes[i] or torch.device(dev) != self.device:
+            return None
+        off = sum(b.sizes[:i])
+        v = b.flat[off:off + b.sizes[i]].view(b.shapes[i])    # a NEW tensor object every time: nothing else references it
+        self._handed[name] = v.data_ptr()
+        return v
+
+    def _world(self):
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def begin_step(self, radii=None):
+        """call between forward and backward of a step: picks the bucket, waits for its previous exchange, clears the leaves'
+        gradients and routes the backward's gradient outputs into the bucket; with `radii` also starts the union-mask exchange"""
+        from diff_gaussian_rasterization import _C
+        b = self.step % len(self.buckets)
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        self.cur = b
+        self._handed = {}
+        for t in self.leaves:
+            t.grad = None
+        self._prev_sink = _C.set_gradient_sink(self._sink)
+        if radii is not None and self.sparse and self._world() > 1:
+            self.announce(radii)
+
+    def announce(self, radii):
+        """all-reduce(max) of the byte mask radii > 0, on a side stream beside the backward"""
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                m = (radii > 0).to(torch.uint8)
+                w = dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        else:
+            m = (radii > 0).to(torch.uint8)
+            w = dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        self._mask = (w, m)
+        self._stats["mask_bytes"] += int(m.numel())
+
+    def submit(self, radii=None):
+        """call after backward(): starts the exchange of this step's gradients; returns the bucket index"""
+        from diff_gaussian_rasterization import _C
+        _C.set_gradient_sink(getattr(self, "_prev_sink", None))
+        b, bucket = self.cur, self.buckets[self.cur]
+        for i, (n, t) in enumerate(zip(self.names, self.leaves)):
+            g = t.grad
+            if g is not None and g.data_ptr() == bucket.views[i].data_ptr() and g.is_contiguous():
+                self._stats["zero_copy_tensors"] += 1
+            else:
+                if g is None:
+                    bucket.views[i].zero_()
+                else:
+                    bucket.views[i].copy_(g)
+                t.grad = bucket.views[i]
+                self._stats["copied_tensors"] += 1
+        self.cur = None
+        self.step += 1
+        self._stats["steps"] += 1
+        world = self._world()
+        dense_bytes = bucket.flat.numel() * bucket.flat.element_size()
+        self._stats["bytes_dense_equivalent"] += dense_bytes
+        if world == 1:
+            return b
+        idx = None
+        if self.sparse:
+            if self._mask is None and radii is not None:
+                self.announce(radii)
+            if self._mask is not None:
+                w, m = self._mask
+                self._mask = None
+                if self._side is not None:
+                    with torch.cuda.stream(self._side):
+                        w.wait()
+                        idx = m.nonzero(as_tuple=False).flatten()     # host waits for the side stream only
+                    torch.cuda.current_stream(self.device).wait_stream(self._side)
+                else:
+                    w.wait()
+                    idx = m.nonzero(as_tuple=False).flatten()
+                if idx.numel() > self.dense_above * self.P:
+                    idx = None
+        if idx is None:
+            self.pending[b] = bucket.all_reduce(group=self.group, average=self.average, async_op=True)
+            self._stats["bytes_exchanged"] += dense_bytes
+            return b
+        U = int(idx.numel())
+        widths = [n // self.P for n in bucket.sizes]
+        compact = torch.empty(U * sum(widths), dtype=bucket.flat.dtype, device=bucket.flat.device)
+        parts, off = [], 0
+        for v, wd in zip(bucket.views, widths):
+            c = compact[off:off + U * wd].view(U, wd)
+            torch.index_select(v.reshape(self.P, wd), 0, idx, out=c)
+            parts.append(c)
+            off += U * wd
+        work = dist.all_reduce(compact, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending[b] = _SparsePending(work, compact, parts, [v.reshape(self.P, wd) for v, wd in zip(bucket.views, widths)], idx,
+                                         1.0 / world if self.average else None)
+        self._stats["bytes_exchanged"] += compact.numel() * compact.element_size()
+        self._stats["sparse_steps"] += 1
+        self._stats["union_rows"] += U
+        return b
+
+    def reduced(self, step):
+        b = step % len(self.buckets)
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        return self.buckets[b].views
+
+    def drain(self):
+        for b in range(len(self.buckets)):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def stats(self):
+        s = dict(self._stats)
+        n = max(1, s["steps"])
+        s["exchange_bytes_per_step"] = (s["bytes_exchanged"] + s["mask_bytes"]) / n
+        s["dense_bytes_per_step"] = s["bytes_dense_equivalent"] / n
+        s["union_fraction"] = (s["union_rows"] / (s["sparse_steps"] * self.P)) if s["sparse_steps"] else None
+        return s
+
+
+class _SparsePending:
+    """handle of a visibility-sparse exchange: wait() completes the all-reduce of the compact rows and scatters them back"""
+
+    def __init__(self, work, compact, parts, views, idx, scale):
+        self.work, self.compact, self.parts, self.views, self.idx, self.scale = work, compact, parts, views, idx, scale
+
+    def wait(self):
+        if self.work is None:
+            return
+        self.work.wait()
+        if self.scale is not None:
+            self.compact.mul_(self.scale)
+        for v, c in zip(self.views, self.parts):
+            v.index_copy_(0, self.idx, c)
+        self.work = None

@@ -144,16 +144,15 @@ def inverse_sigmoid(x):
 
 
 def update_params_and_optimizer(new_params, params, optimizer):
-    """:107-119 — replaces whole tensors (opacity reset) and zeroes their Adam moments."""
-    for k, v in new_params.items():
-        group = [x for x in optimizer.param_groups if x["name"] == k][0]
-        stored_state = optimizer.state.get(group['params'][0], None)
-        stored_state["exp_avg"] = torch.zeros_like(v)
-        stored_state["exp_avg_sq"] = torch.zeros_like(v)
-        del optimizer.state[group['params'][0]]
-        group["params"][0] = torch.nn.Parameter(v.requires_grad_(True))
-        optimizer.state[group['params'][0]] = stored_state
-        params[k] = group["params"][0]
+    """Whole-tensor replacement of parameters (the opacity reset) with their Adam moments restarted from zero — what
+    utils/slam_external.py:107-119 does per key — expressed on the same (name, tensor) table and installer as the prune /
+    append compaction above: the new value becomes the parameter, zeros become its two moments, the state keeps its step."""
+    names, tensors = [], []
+    for key, value in new_params.items():
+        names.append(("param", key)); tensors.append(value)
+        names.append(("exp_avg", key)); tensors.append(torch.zeros_like(value))
+        names.append(("exp_avg_sq", key)); tensors.append(torch.zeros_like(value))
+    _install(names, tensors, params, None, optimizer)
     return params
 
 
@@ -179,21 +178,30 @@ def prune_mask(params, variables, removal_opacity_threshold, remove_big):
     return keep, (scratch, kept)
 
 
+def _prune_schedule(it, cfg):
+    """what utils/slam_external.py:167-188 does at mapping iteration `it` under the schedule `cfg` (the reference's keys):
+    (opacity threshold to prune at | None, also remove big Gaussians, reset opacities afterwards)"""
+    if it > cfg['stop_after']:
+        return None, False, False
+    threshold = None
+    if it >= cfg['start_after'] and it % cfg['prune_every'] == 0:
+        threshold = cfg['final_removal_opacity_threshold'] if it == cfg['stop_after'] else cfg['removal_opacity_threshold']
+    reset = bool(cfg['reset_opacities']) and it > 0 and it % cfg['reset_opacities_every'] == 0
+    return threshold, it >= cfg['remove_big_after'], reset
+
+
 def prune_gaussians(params, variables, optimizer, iter, prune_dict):
     """utils/slam_external.py:167-188, same schedule keys (start_after, remove_big_after, stop_after, prune_every,
-    removal_opacity_threshold, final_removal_opacity_threshold, reset_opacities, reset_opacities_every)."""
-    if iter <= prune_dict['stop_after']:
-        if (iter >= prune_dict['start_after']) and (iter % prune_dict['prune_every'] == 0):
-            if iter == prune_dict['stop_after']:
-                remove_threshold = prune_dict['final_removal_opacity_threshold']
-            else:
-                remove_threshold = prune_dict['removal_opacity_threshold']
-            keep, scanned = prune_mask(params, variables, remove_threshold, iter >= prune_dict['remove_big_after'])
-            params, variables = remove_points(keep, params, variables, optimizer, _scanned=scanned)
-        # Reset Opacities for all Gaussians
-        if iter > 0 and iter % prune_dict['reset_opacities_every'] == 0 and prune_dict['reset_opacities']:
-            new_params = {'logit_opacities': inverse_sigmoid(torch.ones_like(params['logit_opacities']) * 0.01)}
-            params = update_params_and_optimizer(new_params, params, optimizer)
+    removal_opacity_threshold, final_removal_opacity_threshold, reset_opacities, reset_opacities_every): one fused mask + scan
+    (hsr_prune_mask) and one row compaction over every parameter, Adam moment and bookkeeping vector (hsr_compact_append_rows)
+    instead of ~22 boolean-mask gathers."""
+    threshold, remove_big, reset = _prune_schedule(iter, prune_dict)
+    if threshold is not None:
+        keep, scanned = prune_mask(params, variables, threshold, remove_big)
+        params, variables = remove_points(keep, params, variables, optimizer, _scanned=scanned)
+    if reset:   # every opacity back to 0.01 (:186), moments restarted
+        params = update_params_and_optimizer({'logit_opacities': inverse_sigmoid(torch.full_like(params['logit_opacities'], 0.01))},
+                                             params, optimizer)
     return params, variables
 
 

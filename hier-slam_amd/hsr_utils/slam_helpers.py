@@ -112,10 +112,17 @@ class _FramePrep(torch.autograd.Function):
             return None if g is None else g.contiguous().float()
         g_means, g_tr, g_rot, g_op, g_sc = up(g_means), up(g_tr), up(g_rot), up(g_op), up(g_sc)
         g_sil = up(g_sil) if has_sil else None
-        d_means = torch.empty((P, 3), **o)
-        d_unnorm = torch.empty((P, 4), **o)
-        d_logit = torch.empty_like(logit_opacities)
-        d_ls = torch.empty_like(log_scales)
+        # gradient sink (diff_gaussian_rasterization/_C.py set_gradient_sink): the parameter gradients may be written straight into
+        # views of a communication bucket (hsr_utils/parallel.py GradientExchange)
+        sink = (lambda name, shape: _glue._from_sink("params." + name, shape, dev)) if gaussians_grad else (lambda name, shape: None)
+
+        def alloc(name, shape):
+            t = sink(name, shape)
+            return t if t is not None else torch.empty(shape, **o)
+        d_means = alloc("means3D", (P, 3))
+        d_unnorm = alloc("unnorm_rotations", (P, 4))
+        d_logit = alloc("logit_opacities", tuple(logit_opacities.shape))
+        d_ls = alloc("log_scales", tuple(log_scales.shape))
         d_cam = torch.empty(7, **o)
         scratch = torch.empty(int(_lib.hsr_frame_prep_scratch_bytes(P)), dtype=torch.uint8, device=dev)
 

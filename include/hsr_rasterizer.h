@@ -60,17 +60,20 @@ typedef struct hsr_buffer {
 size_t hsr_required_geometry_bytes(int P);
 size_t hsr_required_image_bytes(int width, int height);
 size_t hsr_required_binning_bytes(int num_rendered);
-/* Size of the optional backward scratch (per-instance gradient rows + inverse permutation) that enables the
- * experimental backward without global atomics; 0 when that path does not cover K (K > 27).  The reference allocates its
- * backward scratch itself with cudaMalloc/cudaFree per call (rasterizer_impl.cu:673-701); here the caller owns it. */
+/* Size of the backward's scratch buffer for the accumulation mode in force: the packed per-Gaussian gradient rows of mode 0
+ * (P rows of a 64-byte-aligned stride that holds the 10 + K sums of one Gaussian: 48 floats at K = 26), which the tile kernel
+ * adds into and the per-Gaussian kernel unpacks into the reference's arrays; 0 in mode 2, which needs none.  The caller owns it
+ * (the reference allocates its backward scratch itself with cudaMalloc/cudaFree per call, rasterizer_impl.cu:673-701).  A call
+ * without scratch, or with too little, falls back to mode 2 for that call. */
 size_t hsr_backward_scratch_bytes(int P, int K, int num_rendered);
-/* How the backward accumulates per-Gaussian sums (process-wide; default 0, or HSR_BWD_IMPL=rows|legacy):
+/* How the backward accumulates per-Gaussian sums (process-wide; default 0, or HSR_BWD_IMPL=legacy):
  *   0 packed : fp32 atomics into one 64-byte-aligned scratch row per Gaussian, unpacked by the per-Gaussian
- *              kernel — about half the atomic requests of the reference's six separate arrays;
- *   1 rows   : per-instance rows + per-Gaussian sum, no global atomics (experimental, K <= 27);
+ *              kernel — about half the atomic requests of the reference's six separate arrays (default);
+ *   1        : refused by this library (HSR_ERR_INVALID_ARGUMENT): the per-instance-rows experiment lives in the
+ *              diagnostic build `make ablate` only;
  *   2 legacy : atomics straight into the six output arrays, as the reference does; needs no scratch. */
 int hsr_set_backward_mode(int mode);
-int hsr_get_backward_mode(void);   /* 0 packed, 1 rows, 2 legacy */
+int hsr_get_backward_mode(void);   /* 0 packed, 2 legacy */
 
 /* Thread-local text of the last error returned by any hsr_* call on this thread. */
 const char* hsr_last_error(void);

@@ -15,6 +15,15 @@
  * instead (tests/): a float64 dense torch.autograd restatement of the forward maths, finite
  * differences, and the algebraic identities the compositing satisfies.
  *
+ * Two builds of this one file (oracle/Makefile):
+ *   libhsr_oracle.so      `real` = float: THE ORACLE.  fp32 wherever the reference is fp32, in its operation order.
+ *   libhsr_oracle_f64.so  -DHSRO_TRUTH, `real` = double: the "truth" build.  The per-Gaussian preprocess — everything that
+ *                         decides an integer (radii, tile rects, keys, sort, ranges) and the fp32 state the tile kernels
+ *                         read (means2D, conic, depth) — is the SAME fp32 code, so both builds walk identical lists; the
+ *                         compositing loop, its backward and the per-Gaussian chain rule run in double on that state.
+ *                         Where the oracle and another fp32 implementation (the HIP kernels) differ by rounding, the truth
+ *                         build says who is closer to exact arithmetic (tests/test_oracle.py, tests/test_gpu_truth.py).
+ *
  * Floating-point policy: everything that decides an INTEGER output (radii, tile rects, tiles_touched,
  * sort keys, ranges) is evaluated in the reference's exact operation order, fp32 (double where the
  * reference promotes), with contraction disabled (build with -ffp-contract=off).
@@ -32,6 +41,17 @@
  * rule 1 uses the list position the FORWARD recorded for the crossing (field "median_pos"), which is what
  * the HIP product does.  Every backward call counts the pixels on which the two rules disagree
  * (hsro_last_median_rule_disagreements()), so a comparison can say how many there were.
+ *
+ * Threshold ties (test aid, not in the reference).  The compositing loop takes hard decisions on computed floats —
+ * power > 0, alpha >= 1/255, T(1-alpha) < 1e-4, T crossing 0.5 — and two correct fp32 evaluations (glibc expf here,
+ * v_exp_f32 in the HIP kernels, CUDA's expf in the reference) can take a decision that falls within ulps of its
+ * threshold differently; the pixel then differs by that splat's whole contribution.  The forward flags such pixels
+ * (tie_pixels) and the splats involved (tie_gaussians), and BOUNDS the difference: for every flagged decision the pixel
+ * is evaluated again with that one decision taken the other way; the sum of |difference| over the flagged decisions of a
+ * pixel is its image bound (tie_img_bound), and the backward does the same for the gradient rows (HsroBounds: per-splat
+ * differences of the accumulated sums, carried through the per-Gaussian chain rule — which is linear in them — and
+ * summed in absolute value per Gaussian).  A comparison may then allow exactly that much on exactly those entries,
+ * instead of leaving them out.
  */
 #include <math.h>
 #include <stdint.h>
@@ -46,6 +66,20 @@
 #define BLOCK_SIZE (BLOCK_X * BLOCK_Y)
 #define NUM_CHANNELS 3 /* config.h:15 */
 
+#ifdef HSRO_TRUTH
+typedef double real;
+#define R_EXP exp
+#define R_FABS fabs
+static inline double sqrt_r(double x) { return sqrt(x); }
+#else
+typedef float real;
+#define R_EXP expf
+#define R_FABS fabsf
+static inline float sqrt_r(float x) { return sqrtf(x); }
+#endif
+static inline float sqrt_f(float x) { return sqrtf(x); }
+int hsro_real_bytes(void) { return (int)sizeof(real); }
+
 /* auxiliary.h:21-37 */
 static const float SH_C0 = 0.28209479177387814f;
 static const float SH_C1 = 0.4886025119029199f;
@@ -55,65 +89,18 @@ static const float SH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.45704
                               0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
                               -0.5900435899266435f};
 
-typedef struct { float x, y, z; } v3;
-typedef struct { float x, y, z, w; } v4;
-/* GLM-style column-major 3x3: m.c[col][row] (glm/detail/type_mat3x3.inl) */
-typedef struct { float c[3][3]; } m3;
+/* the vector / matrix helpers, once in fp32 (forward preprocess: always fp32) and once in `real` (backward chain) */
+#define RT float
+#define LA(x) x##_f
+#include "hsr_oracle_la.h"
+#undef RT
+#undef LA
+#define RT real
+#define LA(x) x##_r
+#include "hsr_oracle_la.h"
+#undef RT
+#undef LA
 
-static inline float fminf_(float a, float b) { return a < b ? a : b; }
-static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
-
-/* glm mat3*mat3, element sums left to right (third_party/glm/glm/detail/type_mat3x3.inl:486-520) */
-static m3 m3_mul(const m3* a, const m3* b)
-{
-    m3 r;
-    for (int c = 0; c < 3; c++)
-        for (int rr = 0; rr < 3; rr++)
-            r.c[c][rr] = a->c[0][rr] * b->c[c][0] + a->c[1][rr] * b->c[c][1] + a->c[2][rr] * b->c[c][2];
-    return r;
-}
-static m3 m3_transpose(const m3* a)
-{
-    m3 r;
-    for (int c = 0; c < 3; c++)
-        for (int rr = 0; rr < 3; rr++) r.c[c][rr] = a->c[rr][c];
-    return r;
-}
-/* glm::mat3(a0..a8): column-major fill */
-static m3 m3_make(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8)
-{
-    m3 r;
-    r.c[0][0] = a0; r.c[0][1] = a1; r.c[0][2] = a2;
-    r.c[1][0] = a3; r.c[1][1] = a4; r.c[1][2] = a5;
-    r.c[2][0] = a6; r.c[2][1] = a7; r.c[2][2] = a8;
-    return r;
-}
-
-/* auxiliary.h:58-66 */
-static v3 transformPoint4x3(v3 p, const float* m)
-{
-    v3 t = {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
-            m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
-            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
-    return t;
-}
-/* auxiliary.h:68-77 */
-static v4 transformPoint4x4(v3 p, const float* m)
-{
-    v4 t = {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
-            m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
-            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14],
-            m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]};
-    return t;
-}
-/* auxiliary.h:89-97 */
-static v3 transformVec4x3Transpose(v3 p, const float* m)
-{
-    v3 t = {m[0] * p.x + m[1] * p.y + m[2] * p.z,
-            m[4] * p.x + m[5] * p.y + m[6] * p.z,
-            m[8] * p.x + m[9] * p.y + m[10] * p.z};
-    return t;
-}
 /* auxiliary.h:41-44: double arithmetic, rounded to float on return */
 static float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
@@ -126,18 +113,6 @@ static void getRect(float px, float py, int max_radius, uint32_t* rminx, uint32_
     a = (int)((py - max_radius) / BLOCK_Y); if (a < 0) a = 0; *rminy = (uint32_t)a < gy ? (uint32_t)a : gy;
     a = (int)((px + max_radius + BLOCK_X - 1) / BLOCK_X); if (a < 0) a = 0; *rmaxx = (uint32_t)a < gx ? (uint32_t)a : gx;
     a = (int)((py + max_radius + BLOCK_Y - 1) / BLOCK_Y); if (a < 0) a = 0; *rmaxy = (uint32_t)a < gy ? (uint32_t)a : gy;
-}
-
-/* auxiliary.h:107-118 */
-static v3 dnormvdv3(v3 v, v3 dv)
-{
-    float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
-    float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-    v3 r;
-    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
-    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
-    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
-    return r;
 }
 
 /* rasterizer_impl.cu:35-50 */
@@ -154,26 +129,26 @@ uint32_t hsro_get_higher_msb(uint32_t n)
 }
 
 /* auxiliary.h:139-164 (prefiltered trap omitted: the oracle has no device to trap) */
-static int in_frustum(int idx, const float* pts, const float* view, const float* proj, v3* p_view)
+static int in_frustum(int idx, const float* pts, const float* view, const float* proj, v3_f* p_view)
 {
-    v3 p = {pts[3 * idx], pts[3 * idx + 1], pts[3 * idx + 2]};
+    v3_f p = {pts[3 * idx], pts[3 * idx + 1], pts[3 * idx + 2]};
     (void)proj; /* p_hom / p_proj are computed but unused by the reference's test */
-    *p_view = transformPoint4x3(p, view);
+    *p_view = transformPoint4x3_f(p, view);
     return !(p_view->z <= 0.2f);
 }
 
 /* rasterizer_impl.cu:54-66, :141-153 */
 void hsro_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present)
 {
-    for (int i = 0; i < P; i++) { v3 pv; present[i] = (uint8_t)in_frustum(i, means3D, view, proj, &pv); }
+    for (int i = 0; i < P; i++) { v3_f pv; present[i] = (uint8_t)in_frustum(i, means3D, view, proj, &pv); }
 }
 
 /* forward.cu:20-71 */
-static v3 computeColorFromSH(int idx, int deg, int max_coeffs, const float* means, const float* campos,
-                             const float* shs, uint8_t* clamped)
+static v3_f computeColorFromSH(int idx, int deg, int max_coeffs, const float* means, const float* campos,
+                               const float* shs, uint8_t* clamped)
 {
-    v3 pos = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
-    v3 dir = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
+    v3_f pos = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
+    v3_f dir = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
     float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
     dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
     const float* sh = shs + (size_t)idx * max_coeffs * 3;
@@ -202,45 +177,27 @@ static v3 computeColorFromSH(int idx, int deg, int max_coeffs, const float* mean
         clamped[3 * idx + c] = (r < 0);
         res[c] = r > 0.0f ? r : 0.0f;
     }
-    v3 out = {res[0], res[1], res[2]};
+    v3_f out = {res[0], res[1], res[2]};
     return out;
 }
 
 /* forward.cu:118-152 */
-static void computeCov3D(v3 scale, float mod, v4 rot, float* cov3D)
+static void computeCov3D(v3_f scale, float mod, v4_f rot, float* cov3D)
 {
-    m3 S = m3_make(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    m3_f S = m3_make_f(1, 0, 0, 0, 1, 0, 0, 0, 1);
     S.c[0][0] = mod * scale.x; S.c[1][1] = mod * scale.y; S.c[2][2] = mod * scale.z;
     float r = rot.x, x = rot.y, y = rot.z, z = rot.w; /* not normalised: forward.cu:127 */
-    m3 R = m3_make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
-                   2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
-                   2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
-    m3 M = m3_mul(&S, &R);
-    m3 Mt = m3_transpose(&M);
-    m3 Sigma = m3_mul(&Mt, &M);
+    m3_f R = m3_make_f(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                       2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                       2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    m3_f M = m3_mul_f(&S, &R);
+    m3_f Mt = m3_transpose_f(&M);
+    m3_f Sigma = m3_mul_f(&Mt, &M);
     cov3D[0] = Sigma.c[0][0]; cov3D[1] = Sigma.c[0][1]; cov3D[2] = Sigma.c[0][2];
     cov3D[3] = Sigma.c[1][1]; cov3D[4] = Sigma.c[1][2]; cov3D[5] = Sigma.c[2][2];
 }
 
-/* shared by forward.cu:74-113 and backward.cu:166-199: T = W*J and cov2D (before the +0.3) */
-static void cov2d_core(v3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy, const float* cov3D,
-                       const float* view, v3* t_out, float* txtz_o, float* tytz_o, m3* T_out, m3* Vrk_out, m3* cov_out)
-{
-    v3 t = transformPoint4x3(mean, view);
-    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-    const float txtz = t.x / t.z, tytz = t.y / t.z;
-    t.x = fminf_(limx, fmaxf_(-limx, txtz)) * t.z;
-    t.y = fminf_(limy, fmaxf_(-limy, tytz)) * t.z;
-    m3 J = m3_make(focal_x / t.z, 0.0f, -(focal_x * t.x) / (t.z * t.z),
-                   0.0f, focal_y / t.z, -(focal_y * t.y) / (t.z * t.z), 0, 0, 0);
-    m3 W = m3_make(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
-    m3 T = m3_mul(&W, &J);
-    m3 Vrk = m3_make(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
-    m3 Tt = m3_transpose(&T), Vt = m3_transpose(&Vrk);
-    m3 A = m3_mul(&Tt, &Vt);
-    *cov_out = m3_mul(&A, &T);
-    *t_out = t; *txtz_o = txtz; *tytz_o = tytz; *T_out = T; *Vrk_out = Vrk;
-}
+#define HSRO_IMG_BOUNDS 6   /* tie_img_bound planes: colour (max over channels), depth, opacity, semantic (max over channels), final_T, mask */
 
 typedef struct HsroState {
     int P, W, H, K, semantic, R, tiles_x, tiles_y, has_sh, own_cov3d;
@@ -256,15 +213,17 @@ typedef struct HsroState {
     uint64_t *keys_unsorted, *keys; /* [R]                                (BinningState)                */
     uint32_t *vals_unsorted, *vals; /* [R]                                                              */
     uint32_t* ranges;       /* [T,2]                                      (ImageState.ranges)           */
-    float* final_T;         /* [N]                                        (ImageState.accum_alpha)      */
+    real* final_T;          /* [N]                                        (ImageState.accum_alpha)      */
     uint32_t* n_contrib;    /* [N]                                        (ImageState.n_contrib)        */
     uint32_t* median_pos;   /* [N] 1 + list position of the splat at which T crossed 0.5 (0: never); not in the reference */
-    /* Test aid, not in the reference: where a comparison with ANOTHER fp32 implementation of this loop may legitimately differ by a whole
-     * contribution.  The loop takes hard decisions on computed floats — power > 0, alpha >= 1/255, T(1-alpha) < 1e-4, T crossing 0.5 — and
-     * expf / exp2 implementations differ in the last ulps.  tie_pixels[pix] != 0: some decision of that pixel was taken within HSRO_TIE_EPS
-     * (relative) of its threshold; tie_gaussians[id] != 0: the splat contributes to such a pixel (its gradient rows see the difference). */
+    /* Test aid, not in the reference (file header, "Threshold ties"): tie_pixels[pix] != 0: some decision of that pixel was taken
+     * within HSRO_TIE_EPS (relative) of its threshold; tie_gaussians[id] != 0: the splat contributes to such a pixel (its gradient rows
+     * see the difference); tie_img_bound[plane][pix]: how far the pixel's outputs move when the flagged decisions are taken the other
+     * way (INFINITY where a pixel had more flagged decisions than are tracked). */
     uint8_t* tie_pixels;    /* [N] */
     uint8_t* tie_gaussians; /* [P] */
+    real* tie_img_bound;    /* [HSRO_IMG_BOUNDS, N] */
+    const float* feat;      /* colours the forward blended (caller's colors_precomp or rgb); valid while the caller keeps its inputs */
 } HsroState;
 
 #define HSRO_TIE_EPS 2e-6f   /* a few ulps of alpha; T drifts by less over a tile's list (same fp32 products, alpha differing in the last ulp) */
@@ -280,7 +239,7 @@ void hsro_free(HsroState* s)
     free(s->depths); free(s->means2D); free(s->conic_opacity); free(s->cov3D); free(s->rgb); free(s->clamped);
     free(s->radii); free(s->tiles_touched); free(s->point_offsets); free(s->keys_unsorted); free(s->keys);
     free(s->vals_unsorted); free(s->vals); free(s->ranges); free(s->final_T); free(s->n_contrib);
-    free(s->median_pos); free(s->tie_pixels); free(s->tie_gaussians);
+    free(s->median_pos); free(s->tie_pixels); free(s->tie_gaussians); free(s->tie_img_bound);
     free(s);
 }
 
@@ -294,6 +253,7 @@ const void* hsro_field(const HsroState* s, int id)
     case 8: return s->point_offsets; case 9: return s->keys_unsorted; case 10: return s->keys;
     case 11: return s->vals_unsorted; case 12: return s->vals; case 13: return s->ranges; case 14: return s->final_T;
     case 15: return s->n_contrib; case 16: return s->median_pos; case 17: return s->tie_pixels; case 18: return s->tie_gaussians;
+    case 19: return s->tie_img_bound;
     default: return 0;
     }
 }
@@ -321,20 +281,79 @@ static void stable_sort_pairs(const uint64_t* kin, const uint32_t* vin, uint64_t
     free(ka); free(va); free(kb); free(vb); free(cnt);
 }
 
+/* ---- one pixel of renderCUDA (forward.cu:261-398) / renderCUDA_SEM (forward.cu:400-538) ----
+ * A flagged decision: list index + which test.  kind 1: power > 0; 2: alpha < 1/255; 3: T(1 - alpha) < 1e-4; 4: T crossing 0.5.
+ * `ovr` (pos, kind 1..3) takes that one test the other way (the tie bounds); kind 0: none. */
+typedef struct { uint32_t pos; int kind; } HsroDecision;
+#define HSRO_MAX_DECISIONS 24
+typedef struct {
+    real C[NUM_CHANNELS], D, M, median_D, T;
+    uint32_t last_contributor, median_at, i_end;
+    int ndec, overflow;
+    HsroDecision dec[HSRO_MAX_DECISIONS];
+} HsroPixFwd;
+
+static void pixel_forward(const HsroState* s, const float* feat, const float* semantics, int K, uint32_t r0, uint32_t r1,
+                          float pfx, float pfy, HsroDecision ovr, int collect, real* Sacc, HsroPixFwd* o)
+{
+    real T = 1.0f; uint32_t contributor = 0, last_contributor = 0;
+    real C[NUM_CHANNELS] = {0, 0, 0}; real Dd = 0; real median_D = 15.0f; real Mm = 0;
+    uint32_t median_at = 0;
+    for (int ch = 0; ch < K; ch++) Sacc[ch] = 0;
+    o->ndec = 0; o->overflow = 0; o->i_end = r1;
+#define FLAG(kind_) do { if (collect) { if (o->ndec < HSRO_MAX_DECISIONS) { o->dec[o->ndec].pos = i; o->dec[o->ndec].kind = (kind_); o->ndec++; } else o->overflow = 1; } } while (0)
+    for (uint32_t i = r0; i < r1; i++) {
+        contributor++;
+        uint32_t id = s->vals[i];
+        real dx = (real)s->means2D[2 * id] - (real)pfx, dy = (real)s->means2D[2 * id + 1] - (real)pfy;
+        const float* co = s->conic_opacity + 4 * (size_t)id;
+        real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        /* how far two correct fp32 evaluations of `power` can be apart: a few roundings of its three terms (the reference's
+         * own nvcc build contracts them into FMAs; the HIP path evaluates a pre-scaled form) — relative to alpha that is an
+         * ABSOLUTE difference in power, which for elongated splats (large cancelling terms) is far more than an ulp of alpha */
+        const real pw_slack = 4.0f * 5.96e-8f * (0.5f * (R_FABS(co[0] * dx * dx) + R_FABS(co[2] * dy * dy)) + R_FABS(co[1] * dx * dy));
+        if (R_FABS(power) <= 1e-6f + pw_slack && co[3] >= 1.0f / 255.0f) FLAG(1);
+        int skip = power > 0.0f;
+        if (ovr.kind == 1 && ovr.pos == i) skip = !skip;
+        if (skip) continue;
+        real alpha = fmin_r(0.99f, co[3] * R_EXP(power));
+        if (R_FABS(alpha - 1.0f / 255.0f) <= (HSRO_TIE_EPS + pw_slack) * (1.0f / 255.0f)) FLAG(2);
+        skip = alpha < 1.0f / 255.0f;
+        if (ovr.kind == 2 && ovr.pos == i) skip = !skip;
+        if (skip) continue;
+        real test_T = T * (1 - alpha);
+        if (R_FABS(test_T - 0.0001f) <= 4.0f * HSRO_TIE_EPS * 0.0001f) FLAG(3);
+        if (R_FABS(T - 0.5f) <= 4.0f * HSRO_TIE_EPS * 0.5f || R_FABS(test_T - 0.5f) <= 4.0f * HSRO_TIE_EPS * 0.5f) FLAG(4);
+        int done = test_T < 0.0001f;
+        if (ovr.kind == 3 && ovr.pos == i) done = !done;
+        if (done) { o->i_end = i + 1; break; } /* done = true (forward.cu:358-362, :496-500) */
+        for (int ch = 0; ch < NUM_CHANNELS; ch++) C[ch] += feat[(size_t)id * NUM_CHANNELS + ch] * alpha * T;
+        Dd += s->depths[id] * alpha * T;
+        if (s->semantic) { for (int ch = 0; ch < K; ch++) Sacc[ch] += semantics[(size_t)id * K + ch] * alpha * T; }
+        else Mm += alpha * T;
+        if (T > 0.5f && test_T < 0.5) { median_D = s->depths[id]; median_at = contributor; } /* forward.cu:371-376, :511-515 */
+        T = test_T;
+        last_contributor = contributor;
+    }
+#undef FLAG
+    for (int ch = 0; ch < NUM_CHANNELS; ch++) o->C[ch] = C[ch];
+    o->D = Dd; o->M = Mm; o->median_D = median_D; o->T = T; o->last_contributor = last_contributor; o->median_at = median_at;
+}
+
 /*
  * Forward.  Follows Rasterizer::forward (rasterizer_impl.cu:198-345) when `semantics == NULL`
  * (outputs colour, depth, median depth, opacity, mask) and Rasterizer::forward_semantic
  * (rasterizer_impl.cu:460-610) otherwise (colour, semantic[K], depth, median depth, opacity).
  * All pointers are host pointers; absent optionals are NULL (the reference's `data_ptr()==nullptr`
- * switches, rasterizer_impl.cu:588, forward.cu:205, :241).
+ * switches, rasterizer_impl.cu:588, forward.cu:205, :241).  Image outputs are `real` (float, or double in the truth build).
  * Returns a state handle (the reference's geom/binning/img buffers) or NULL on allocation failure.
  */
 HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int width, int height,
                         const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                        const float* cam_pos, float tan_fovx, float tan_fovy, float* out_color, float* out_semantic,
-                        float* out_depth, float* out_median_depth, float* out_opacity, float* out_mask, int* radii_out)
+                        const float* cam_pos, float tan_fovx, float tan_fovy, real* out_color, real* out_semantic,
+                        real* out_depth, real* out_median_depth, real* out_opacity, real* out_mask, int* radii_out)
 {
     (void)background; /* forward never composites the background (forward.cu:391-392, :530-531) */
     HsroState* s = (HsroState*)calloc(1, sizeof(HsroState));
@@ -349,35 +368,36 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
     s->depths = (float*)calloc(Pa, 4); s->means2D = (float*)calloc(Pa * 2, 4); s->conic_opacity = (float*)calloc(Pa * 4, 4);
     s->cov3D = (float*)calloc(Pa * 6, 4); s->rgb = (float*)calloc(Pa * 3, 4); s->clamped = (uint8_t*)calloc(Pa * 3, 1);
     s->radii = (int*)calloc(Pa, 4); s->tiles_touched = (uint32_t*)calloc(Pa, 4); s->point_offsets = (uint32_t*)calloc(Pa, 4);
-    s->ranges = (uint32_t*)calloc(Tn * 2, 4); s->final_T = (float*)calloc(N, 4); s->n_contrib = (uint32_t*)calloc(N, 4);
+    s->ranges = (uint32_t*)calloc(Tn * 2, 4); s->final_T = (real*)calloc(N, sizeof(real)); s->n_contrib = (uint32_t*)calloc(N, 4);
     s->median_pos = (uint32_t*)calloc(N, 4);
     s->tie_pixels = (uint8_t*)calloc(N, 1); s->tie_gaussians = (uint8_t*)calloc(Pa, 1);
+    s->tie_img_bound = (real*)calloc(N * HSRO_IMG_BOUNDS, sizeof(real));
     s->has_sh = colors_precomp == 0; s->own_cov3d = cov3D_precomp == 0;
 
     /* rasterizer_impl.cu:226-227 */
     const float focal_y = height / (2.0f * tan_fovy);
     const float focal_x = width / (2.0f * tan_fovx);
 
-    /* ---- preprocessCUDA, forward.cu:155-256 ---- */
+    /* ---- preprocessCUDA, forward.cu:155-256 (fp32 in every build) ---- */
 #pragma omp parallel for schedule(static)
     for (int idx = 0; idx < P; idx++) {
         s->radii[idx] = 0; s->tiles_touched[idx] = 0;
-        v3 p_view;
+        v3_f p_view;
         if (!in_frustum(idx, means3D, viewmatrix, projmatrix, &p_view)) continue;
-        v3 p_orig = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-        v4 p_hom = transformPoint4x4(p_orig, projmatrix);
+        v3_f p_orig = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        v4_f p_hom = transformPoint4x4_f(p_orig, projmatrix);
         float p_w = 1.0f / (p_hom.w + 0.0000001f);
-        v3 p_proj = {p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w};
+        v3_f p_proj = {p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w};
         const float* cov3D;
         if (cov3D_precomp) cov3D = cov3D_precomp + (size_t)idx * 6;
         else {
-            v3 sc = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
-            v4 q = {rotations[4 * idx], rotations[4 * idx + 1], rotations[4 * idx + 2], rotations[4 * idx + 3]};
+            v3_f sc = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
+            v4_f q = {rotations[4 * idx], rotations[4 * idx + 1], rotations[4 * idx + 2], rotations[4 * idx + 3]};
             computeCov3D(sc, scale_modifier, q, s->cov3D + (size_t)idx * 6);
             cov3D = s->cov3D + (size_t)idx * 6;
         }
-        v3 t; float txtz, tytz; m3 T, Vrk, cv;
-        cov2d_core(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &t, &txtz, &tytz, &T, &Vrk, &cv);
+        v3_f t; float txtz, tytz; m3_f T, Vrk, cv;
+        cov2d_core_f(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &t, &txtz, &tytz, &T, &Vrk, &cv);
         cv.c[0][0] += 0.3f; cv.c[1][1] += 0.3f;                       /* forward.cu:110-111 */
         const float cx = cv.c[0][0], cy = cv.c[0][1], cz = cv.c[1][1];
         float det = (cx * cz - cy * cy);                                /* forward.cu:219 */
@@ -385,15 +405,15 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
         float det_inv = 1.f / det;
         float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
         float mid = 0.5f * (cx + cz);
-        float lambda1 = mid + sqrtf(fmaxf_(0.1f, mid * mid - det));
-        float lambda2 = mid - sqrtf(fmaxf_(0.1f, mid * mid - det));
-        float my_radius = ceilf(3.f * sqrtf(fmaxf_(lambda1, lambda2)));
+        float lambda1 = mid + sqrtf(fmax_f(0.1f, mid * mid - det));
+        float lambda2 = mid - sqrtf(fmax_f(0.1f, mid * mid - det));
+        float my_radius = ceilf(3.f * sqrtf(fmax_f(lambda1, lambda2)));
         float pix = ndc2Pix(p_proj.x, W), piy = ndc2Pix(p_proj.y, H);
         uint32_t rminx, rminy, rmaxx, rmaxy;
         getRect(pix, piy, (int)my_radius, &rminx, &rminy, &rmaxx, &rmaxy, gx, gy);
         if ((rmaxx - rminx) * (rmaxy - rminy) == 0) continue;
         if (colors_precomp == 0) {
-            v3 c = computeColorFromSH(idx, D, M, means3D, cam_pos, shs, s->clamped);
+            v3_f c = computeColorFromSH(idx, D, M, means3D, cam_pos, shs, s->clamped);
             s->rgb[3 * idx] = c.x; s->rgb[3 * idx + 1] = c.y; s->rgb[3 * idx + 2] = c.z;
         }
         s->depths[idx] = p_view.z;
@@ -446,85 +466,71 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
 
     /* ---- renderCUDA (forward.cu:261-398) / renderCUDA_SEM (forward.cu:400-538), one pixel per "thread" ---- */
     const float* feat = colors_precomp ? colors_precomp : s->rgb;
+    s->feat = feat;
+    const HsroDecision no_ovr = {0, 0};
 #pragma omp parallel for schedule(dynamic, 1)
     for (long tile = 0; tile < (long)Tn; tile++) {
         const uint32_t ty = (uint32_t)(tile / gx), tx = (uint32_t)(tile % gx);
         const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
-        float* Sacc = (float*)malloc(sizeof(float) * (size_t)(K > 0 ? K : 1));
+        real* Sacc = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
+        real* Salt = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
         for (int tyy = 0; tyy < BLOCK_Y; tyy++)
             for (int txx = 0; txx < BLOCK_X; txx++) {
                 uint32_t px = tx * BLOCK_X + txx, py = ty * BLOCK_Y + tyy;
                 if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
                 size_t pix_id = (size_t)W * py + px;
                 float pfx = (float)px, pfy = (float)py;
-                float T = 1.0f; uint32_t contributor = 0, last_contributor = 0;
-                float C[NUM_CHANNELS] = {0, 0, 0}; float Dd = 0; float median_D = 15.0f; float Mm = 0;
-                uint32_t median_at = 0;
-                for (int ch = 0; ch < K; ch++) Sacc[ch] = 0;
-                int risk = 0; uint32_t i_end = r1;   /* test aid (tie_pixels): decisions taken within HSRO_TIE_EPS of their threshold */
-                for (uint32_t i = r0; i < r1; i++) {
-                    contributor++;
-                    uint32_t id = s->vals[i];
-                    float dx = s->means2D[2 * id] - pfx, dy = s->means2D[2 * id + 1] - pfy;
-                    const float* co = s->conic_opacity + 4 * (size_t)id;
-                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    /* how far two correct fp32 evaluations of `power` can be apart: a few roundings of its three terms (the reference's
-                     * own nvcc build contracts them into FMAs; the HIP path evaluates a pre-scaled form) — relative to alpha that is an
-                     * ABSOLUTE difference in power, which for elongated splats (large cancelling terms) is far more than an ulp of alpha */
-                    const float pw_slack = 4.0f * 5.96e-8f * (0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy));
-                    if (fabsf(power) <= 1e-6f + pw_slack && co[3] >= 1.0f / 255.0f) risk = 1;
-                    if (power > 0.0f) continue;
-                    float alpha = fminf_(0.99f, co[3] * expf(power));
-                    if (fabsf(alpha - 1.0f / 255.0f) <= (HSRO_TIE_EPS + pw_slack) * (1.0f / 255.0f)) risk = 1;
-                    if (alpha < 1.0f / 255.0f) continue;
-                    float test_T = T * (1 - alpha);
-                    if (fabsf(test_T - 0.0001f) <= 4.0f * HSRO_TIE_EPS * 0.0001f) risk = 1;
-                    if (fabsf(T - 0.5f) <= 4.0f * HSRO_TIE_EPS * 0.5f || fabsf(test_T - 0.5f) <= 4.0f * HSRO_TIE_EPS * 0.5f) risk = 1;
-                    if (test_T < 0.0001f) { i_end = i + 1; break; } /* done = true (forward.cu:358-362, :496-500) */
-                    for (int ch = 0; ch < NUM_CHANNELS; ch++) C[ch] += feat[(size_t)id * NUM_CHANNELS + ch] * alpha * T;
-                    Dd += s->depths[id] * alpha * T;
-                    if (s->semantic) { for (int ch = 0; ch < K; ch++) Sacc[ch] += semantics[(size_t)id * K + ch] * alpha * T; }
-                    else Mm += alpha * T;
-                    if (T > 0.5f && test_T < 0.5) { median_D = s->depths[id]; median_at = contributor; } /* forward.cu:371-376, :511-515 */
-                    T = test_T;
-                    last_contributor = contributor;
-                }
-                s->final_T[pix_id] = T; s->n_contrib[pix_id] = last_contributor; s->median_pos[pix_id] = median_at;
-                if (risk) {   /* every splat that reaches (or nearly reaches) alpha >= 1/255 on this pixel sees the difference */
+                HsroPixFwd f;
+                pixel_forward(s, feat, semantics, K, r0, r1, pfx, pfy, no_ovr, 1, Sacc, &f);
+                s->final_T[pix_id] = f.T; s->n_contrib[pix_id] = f.last_contributor; s->median_pos[pix_id] = f.median_at;
+                if (f.ndec || f.overflow) {
                     s->tie_pixels[pix_id] = 1;
-                    for (uint32_t i = r0; i < i_end; i++) {
+                    /* every splat that reaches (or nearly reaches) alpha >= 1/255 on this pixel sees the difference */
+                    for (uint32_t i = r0; i < f.i_end; i++) {
                         uint32_t id = s->vals[i];
-                        float dx = s->means2D[2 * id] - pfx, dy = s->means2D[2 * id + 1] - pfy;
+                        real dx = (real)s->means2D[2 * id] - (real)pfx, dy = (real)s->means2D[2 * id + 1] - (real)pfy;
                         const float* co = s->conic_opacity + 4 * (size_t)id;
-                        float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                        const float pw_slack = 4.0f * 5.96e-8f * (0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy));
+                        real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        const real pw_slack = 4.0f * 5.96e-8f * (0.5f * (R_FABS(co[0] * dx * dx) + R_FABS(co[2] * dy * dy)) + R_FABS(co[1] * dx * dy));
                         if (power > 1e-6f + pw_slack) continue;
-                        if (fminf_(0.99f, co[3] * expf(power)) >= (1.0f / 255.0f) * (1.0f - HSRO_TIE_EPS - pw_slack)) s->tie_gaussians[id] = 1;   /* benign race: all writers store 1 */
+                        if (fmin_r(0.99f, co[3] * R_EXP(power)) >= (1.0f / 255.0f) * (1.0f - HSRO_TIE_EPS - pw_slack)) s->tie_gaussians[id] = 1;   /* benign race: all writers store 1 */
                     }
+                    /* the bound: each flagged decision taken the other way, one at a time */
+                    real* b = s->tie_img_bound;
+                    for (int d = 0; d < f.ndec; d++) {
+                        if (f.dec[d].kind == 4) continue;   /* the crossing moves the median depth only: counted, not bounded (median_pos) */
+                        HsroPixFwd g;
+                        pixel_forward(s, feat, semantics, K, r0, r1, pfx, pfy, f.dec[d], 0, Salt, &g);
+                        real dc = 0, ds = 0;
+                        for (int ch = 0; ch < NUM_CHANNELS; ch++) dc = fmax_r(dc, R_FABS(g.C[ch] - f.C[ch]));
+                        if (s->semantic) for (int ch = 0; ch < K; ch++) ds = fmax_r(ds, R_FABS(Salt[ch] - Sacc[ch]));
+                        b[0 * N + pix_id] += dc; b[1 * N + pix_id] += R_FABS(g.D - f.D); b[2 * N + pix_id] += R_FABS(g.T - f.T);
+                        b[3 * N + pix_id] += ds; b[4 * N + pix_id] += R_FABS(g.T - f.T); b[5 * N + pix_id] += R_FABS(g.M - f.M);
+                    }
+                    if (f.overflow) for (int pl = 0; pl < HSRO_IMG_BOUNDS; pl++) b[pl * N + pix_id] = INFINITY;
                 }
-                for (int ch = 0; ch < NUM_CHANNELS; ch++) out_color[(size_t)ch * N + pix_id] = C[ch];
-                out_depth[pix_id] = Dd; out_median_depth[pix_id] = median_D; out_opacity[pix_id] = 1 - T;
+                for (int ch = 0; ch < NUM_CHANNELS; ch++) out_color[(size_t)ch * N + pix_id] = f.C[ch];
+                out_depth[pix_id] = f.D; out_median_depth[pix_id] = f.median_D; out_opacity[pix_id] = 1 - f.T;
                 if (s->semantic) { for (int ch = 0; ch < K; ch++) out_semantic[(size_t)ch * N + pix_id] = Sacc[ch]; }
-                else if (out_mask) out_mask[pix_id] = Mm;
+                else if (out_mask) out_mask[pix_id] = f.M;
             }
-        free(Sacc);
+        free(Sacc); free(Salt);
     }
     return s;
 }
 
 /* backward.cu:20-139 */
 static void computeColorFromSH_bwd(int idx, int deg, int max_coeffs, const float* means, const float* campos, const float* shs,
-                                   const uint8_t* clamped, const float* dL_dcolor, float* dL_dmeans, float* dL_dshs)
+                                   const uint8_t* clamped, const real* dL_dcolor3, real* dL_dmeans3, real* dsh)
 {
-    v3 pos = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
-    v3 dir_orig = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
-    float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
-    float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    v3_r pos = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
+    v3_r dir_orig = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
+    real len = sqrt_r(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    real x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
     const float* sh = shs + (size_t)idx * max_coeffs * 3;
-    float* dsh = dL_dshs + (size_t)idx * max_coeffs * 3;
-    float dRGB[3];
-    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[3 * idx + c] * (clamped[3 * idx + c] ? 0.f : 1.f);
-    float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+    real dRGB[3];
+    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor3[c] * (clamped[3 * idx + c] ? 0.f : 1.f);
+    real dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
 #define SH(i) sh[(i) * 3 + c]
 #define DSH(i, v) for (int c = 0; c < 3; c++) dsh[(i) * 3 + c] = (v) * dRGB[c]
     DSH(0, SH_C0);
@@ -532,7 +538,7 @@ static void computeColorFromSH_bwd(int idx, int deg, int max_coeffs, const float
         DSH(1, -SH_C1 * y); DSH(2, SH_C1 * z); DSH(3, -SH_C1 * x);
         for (int c = 0; c < 3; c++) { dRGBdx[c] = -SH_C1 * SH(3); dRGBdy[c] = -SH_C1 * SH(1); dRGBdz[c] = SH_C1 * SH(2); }
         if (deg > 1) {
-            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
             DSH(4, SH_C2[0] * xy); DSH(5, SH_C2[1] * yz); DSH(6, SH_C2[2] * (2.f * zz - xx - yy));
             DSH(7, SH_C2[3] * xz); DSH(8, SH_C2[4] * (xx - yy));
             for (int c = 0; c < 3; c++) {
@@ -560,31 +566,289 @@ static void computeColorFromSH_bwd(int idx, int deg, int max_coeffs, const float
     }
 #undef SH
 #undef DSH
-    v3 dL_ddir = {dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2],
-                  dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2],
-                  dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2]};
-    v3 dm = dnormvdv3(dir_orig, dL_ddir);
-    dL_dmeans[3 * idx] += dm.x; dL_dmeans[3 * idx + 1] += dm.y; dL_dmeans[3 * idx + 2] += dm.z;
+    v3_r dL_ddir = {dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2],
+                    dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2],
+                    dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2]};
+    v3_r dm = dnormvdv3_r(dir_orig, dL_ddir);
+    dL_dmeans3[0] += dm.x; dL_dmeans3[1] += dm.y; dL_dmeans3[2] += dm.z;
+}
+
+/* ---- the per-Gaussian chain rule: computeCov2DCUDA (backward.cu:144-274) then preprocessCUDA (backward.cu:346-412, also the
+ * semantic path, :1117) for ONE Gaussian, as a function of the sums the tile pass accumulated for it.  It is linear in those
+ * sums, which is what lets the tie bounds carry a per-splat DIFFERENCE of the sums through it. ---- */
+typedef struct {
+    const HsroState* s;
+    int D, M;
+    const float *means3D, *shs, *scales, *rotations, *cov3Ds, *viewmatrix, *projmatrix, *campos;
+    float scale_modifier, focal_x, focal_y, tan_fovx, tan_fovy;
+} HsroChain;
+/* in: dL_dmean2D.xy, dL_dconic.{x,y,w}, dL_ddepth, dL_dcolor.rgb (the last only feeds the SH path).
+ * out: dL_dmean3D[3], dL_dcov3D[6], dL_dscale[3] / dL_drot[4] (when scales given), dL_dsh[M,3] (when shs given; may be NULL) */
+static void gauss_chain(const HsroChain* c, int idx, const real in[9], real* dmean3D, real* dcov, real* dscale, real* drot, real* dsh)
+{
+    const float* cov3D = c->cov3Ds + 6 * (size_t)idx;
+    const float* means3D = c->means3D;
+    v3_r mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    const real dcx = in[2], dcy = in[3], dcz = in[4];
+    v3_r t; real txtz, tytz; m3_r T, Vrk, c2;
+    cov2d_core_r(mean, c->focal_x, c->focal_y, c->tan_fovx, c->tan_fovy, cov3D, c->viewmatrix, &t, &txtz, &tytz, &T, &Vrk, &c2);
+    const real limx = 1.3f * c->tan_fovx, limy = 1.3f * c->tan_fovy;
+    const real x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const real y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    real a = c2.c[0][0] + 0.3f, b = c2.c[0][1], cc = c2.c[1][1] + 0.3f;
+    real denom = a * cc - b * b;
+    real dL_da = 0, dL_db = 0, dL_dc = 0;
+    real denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define TT(i, j) T.c[i][j]
+#define VV(i, j) Vrk.c[i][j]
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-cc * cc * dcx + 2 * b * cc * dcy + (denom - a * cc) * dcz);
+        dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * cc) * dcx);
+        dL_db = denom2inv * 2 * (b * cc * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+        dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+        dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+        dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+        dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+        dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+        dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+    } else {
+        for (int i = 0; i < 6; i++) dcov[i] = 0;
+    }
+    real dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
+                   (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+    real dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
+                   (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+    real dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
+                   (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+    real dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
+                   (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+    real dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
+                   (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+    real dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
+                   (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+#undef TT
+#undef VV
+    /* W as built at backward.cu:182-185: W[c][r] */
+    const float* vm = c->viewmatrix;
+    m3_r Wm = m3_make_r(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+    real dL_dJ00 = Wm.c[0][0] * dL_dT00 + Wm.c[0][1] * dL_dT01 + Wm.c[0][2] * dL_dT02;
+    real dL_dJ02 = Wm.c[2][0] * dL_dT00 + Wm.c[2][1] * dL_dT01 + Wm.c[2][2] * dL_dT02;
+    real dL_dJ11 = Wm.c[1][0] * dL_dT10 + Wm.c[1][1] * dL_dT11 + Wm.c[1][2] * dL_dT12;
+    real dL_dJ12 = Wm.c[2][0] * dL_dT10 + Wm.c[2][1] * dL_dT11 + Wm.c[2][2] * dL_dT12;
+    real tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float h_x = c->focal_x, h_y = c->focal_y;
+    real dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    real dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    real dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+    v3_r dt = {dL_dtx, dL_dty, dL_dtz};
+    v3_r dm = transformVec4x3Transpose_r(dt, c->viewmatrix);
+    dmean3D[0] = dm.x; dmean3D[1] = dm.y; dmean3D[2] = dm.z; /* assignment, :273 */
+
+    /* ---- preprocessCUDA (backward), backward.cu:346-412 ---- */
+    v3_r m = mean;
+    const float* proj = c->projmatrix; const float* view = c->viewmatrix;
+    v4_r m_hom = transformPoint4x4_r(m, proj);
+    real m_w = 1.0f / (m_hom.w + 0.0000001f);
+    real mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+    real mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+    const real d2x = in[0], d2y = in[1];
+    real gxm = (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
+    real gym = (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
+    real gzm = (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
+    dmean3D[0] += gxm; dmean3D[1] += gym; dmean3D[2] += gzm;
+    real mul3 = view[2] * m.x + view[6] * m.y + view[10] * m.z + view[14];
+    const real dd = in[5];
+    dmean3D[0] += (view[2] - view[3] * mul3) * dd;
+    dmean3D[1] += (view[6] - view[7] * mul3) * dd;
+    dmean3D[2] += (view[10] - view[11] * mul3) * dd;
+    if (c->shs && dsh) computeColorFromSH_bwd(idx, c->D, c->M, means3D, c->campos, c->shs, c->s->clamped, in + 6, dmean3D, dsh);
+    if (c->scales && dscale && drot) {
+        /* computeCov3D backward, backward.cu:278-341 */
+        const float* rotations = c->rotations; const float* scales = c->scales;
+        real r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
+        m3_r Rm = m3_make_r(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                            2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                            2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+        m3_r S = m3_make_r(1, 0, 0, 0, 1, 0, 0, 0, 1);
+        real sx = c->scale_modifier * scales[3 * idx], sy = c->scale_modifier * scales[3 * idx + 1], sz = c->scale_modifier * scales[3 * idx + 2];
+        S.c[0][0] = sx; S.c[1][1] = sy; S.c[2][2] = sz;
+        m3_r Mm = m3_mul_r(&S, &Rm);
+        const real* dc = dcov;
+        m3_r dSig = m3_make_r(dc[0], 0.5f * dc[1], 0.5f * dc[2], 0.5f * dc[1], dc[3], 0.5f * dc[4], 0.5f * dc[2], 0.5f * dc[4], dc[5]);
+        m3_r M2 = Mm;
+        for (int k = 0; k < 3; k++) for (int rr = 0; rr < 3; rr++) M2.c[k][rr] = 2.0f * Mm.c[k][rr]; /* 2.0f * M */
+        m3_r dL_dM = m3_mul_r(&M2, &dSig);
+        m3_r Rt = m3_transpose_r(&Rm);
+        m3_r dMt = m3_transpose_r(&dL_dM);
+        dscale[0] = Rt.c[0][0] * dMt.c[0][0] + Rt.c[0][1] * dMt.c[0][1] + Rt.c[0][2] * dMt.c[0][2];
+        dscale[1] = Rt.c[1][0] * dMt.c[1][0] + Rt.c[1][1] * dMt.c[1][1] + Rt.c[1][2] * dMt.c[1][2];
+        dscale[2] = Rt.c[2][0] * dMt.c[2][0] + Rt.c[2][1] * dMt.c[2][1] + Rt.c[2][2] * dMt.c[2][2];
+        for (int k = 0; k < 3; k++) { dMt.c[0][k] *= sx; dMt.c[1][k] *= sy; dMt.c[2][k] *= sz; }
+#define DM(i, j) dMt.c[i][j]
+        real qx = 2 * z * (DM(0, 1) - DM(1, 0)) + 2 * y * (DM(2, 0) - DM(0, 2)) + 2 * x * (DM(1, 2) - DM(2, 1));
+        real qy = 2 * y * (DM(1, 0) + DM(0, 1)) + 2 * z * (DM(2, 0) + DM(0, 2)) + 2 * r * (DM(1, 2) - DM(2, 1)) - 4 * x * (DM(2, 2) + DM(1, 1));
+        real qz = 2 * x * (DM(1, 0) + DM(0, 1)) + 2 * r * (DM(2, 0) - DM(0, 2)) + 2 * z * (DM(1, 2) + DM(2, 1)) - 4 * y * (DM(2, 2) + DM(0, 0));
+        real qw = 2 * r * (DM(0, 1) - DM(1, 0)) + 2 * x * (DM(2, 0) + DM(0, 2)) + 2 * y * (DM(1, 2) + DM(2, 1)) - 4 * z * (DM(1, 1) + DM(0, 0));
+#undef DM
+        drot[0] = qx; drot[1] = qy; drot[2] = qz; drot[3] = qw;
+    }
+}
+
+/* ---- one pixel of renderCUDA (backward.cu:472-666) / renderCUDA_SEM (backward.cu:669-899) ----
+ * Adds the pixel's per-splat terms into rows of NA = 10 + K doubles: mean2D xy, conic xyw, opacity, colour rgb, depth, sem[K].
+ * local == NULL: into acc[id] (shared, atomic); else into local[list position - r0] (the tie bounds' private copy). */
+typedef struct {
+    const HsroState* s;
+    const float *colors, *background, *dL_dpix, *dL_dpix_sem, *dL_dpix_depth, *dL_dpix_median, *dL_dpix_opacity;
+    size_t N; int K, NA;
+    real ddelx_dx, ddely_dy;
+    int median_rule;
+} HsroBwdCtx;
+
+static int pixel_backward(const HsroBwdCtx* c, size_t pix_id, float pfx, float pfy, uint32_t r0, uint32_t r1, real T_final,
+                          int last_contributor, uint32_t median_at, HsroDecision ovr, real* dsem, double* acc, double* local)
+{
+    const HsroState* s = c->s;
+    const size_t N = c->N; const int K = c->K, NA = c->NA;
+    real T = T_final;
+    uint32_t contributor = r1 - r0;
+    real accum_rec[NUM_CHANNELS] = {0, 0, 0}, dpx[NUM_CHANNELS], last_color[NUM_CHANNELS] = {0, 0, 0};
+    for (int ch = 0; ch < NUM_CHANNELS; ch++) dpx[ch] = c->dL_dpix[(size_t)ch * N + pix_id];
+    const real dpd = c->dL_dpix_depth[pix_id], dpm = c->dL_dpix_median[pix_id], dpo = c->dL_dpix_opacity[pix_id];
+    for (int ch = 0; ch < K; ch++) dsem[ch] = c->dL_dpix_sem[(size_t)ch * N + pix_id];
+    real accum_depth_rec = 0, accum_op_rec = 0, last_alpha = 0, last_depth = 0, last_op = 0;
+    int pixel_disagrees = 0;
+#define ADD(col, v) do { if (local) a[col] += (double)(v); else { _Pragma("omp atomic") a[col] += (double)(v); } } while (0)
+    for (uint32_t ii = r1; ii > r0; ii--) { /* back to front, backward.cu:562, :771 */
+        contributor--;
+        if ((int64_t)contributor >= (int64_t)last_contributor) continue;
+        uint32_t id = s->vals[ii - 1];
+        real dx = (real)s->means2D[2 * id] - (real)pfx, dy = (real)s->means2D[2 * id + 1] - (real)pfy;
+        const float* co = s->conic_opacity + 4 * (size_t)id;
+        real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        int skip = power > 0.0f;
+        if (ovr.kind == 1 && ovr.pos == ii - 1) skip = !skip;
+        if (skip) continue;
+        const real G = R_EXP(power);
+        const real alpha = fmin_r(0.99f, co[3] * G);
+        skip = alpha < 1.0f / 255.0f;
+        if (ovr.kind == 2 && ovr.pos == ii - 1) skip = !skip;
+        if (skip) continue;
+        real test_T = T / (1.f - alpha);
+        const real w = alpha * test_T;
+        double* a = local ? local + (size_t)(ii - 1 - r0) * NA : acc + (size_t)id * NA;
+        real dL_dalpha = 0.0f;
+        for (int ch = 0; ch < NUM_CHANNELS; ch++) {
+            const real cval = c->colors[(size_t)id * NUM_CHANNELS + ch];
+            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+            last_color[ch] = cval;
+            dL_dalpha += (cval - accum_rec[ch]) * dpx[ch];
+            real v = w * dpx[ch];
+            ADD(6 + ch, v);
+        }
+        /* semantic: s == 0 (unwritten scratch), accum_rec_sem and last_semantic stay 0, so the
+           dL_dalpha term (backward.cu:840) is exactly 0; only dL_dsemantics accumulates (:845) */
+        for (int ch = 0; ch < K; ch++) {
+            real v = w * dsem[ch];
+            ADD(10 + ch, v);
+        }
+        const real c_d = s->depths[id];
+        accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+        last_depth = c_d;
+        dL_dalpha += (c_d - accum_depth_rec) * dpd;
+        {
+            real v = w * dpd;
+            ADD(9, v);
+        }
+        {
+            const int by_reference_rule = (test_T > 0.5f && T < 0.5); /* backward.cu:623-626, :854-857 */
+            const int by_forward_record = (contributor + 1 == median_at);
+            if (by_reference_rule != by_forward_record) pixel_disagrees = 1;
+            if (c->median_rule ? by_forward_record : by_reference_rule) ADD(9, dpm);
+        }
+        accum_op_rec = last_alpha * last_op + (1.f - last_alpha) * accum_op_rec;
+        last_op = 1.f;
+        dL_dalpha += (1.f - accum_op_rec) * dpo;
+        {
+            real v = w * dpo;
+            ADD(5, v);
+        }
+        dL_dalpha *= test_T;
+        T = test_T;
+        last_alpha = alpha;
+        real bg_dot = 0;
+        for (int i = 0; i < NUM_CHANNELS; i++) bg_dot += c->background[i] * dpx[i];
+        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+        const real dL_dG = co[3] * dL_dalpha;
+        const real gdx = G * dx, gdy = G * dy;
+        const real dG_ddelx = -gdx * co[0] - gdy * co[1];
+        const real dG_ddely = -gdy * co[2] - gdx * co[1];
+        real v0 = dL_dG * dG_ddelx * c->ddelx_dx, v1 = dL_dG * dG_ddely * c->ddely_dy;
+        real v2 = -0.5f * gdx * dx * dL_dG, v3_ = -0.5f * gdx * dy * dL_dG, v4_ = -0.5f * gdy * dy * dL_dG;
+        real v5 = G * dL_dalpha;
+        ADD(0, v0); ADD(1, v1); ADD(2, v2); ADD(3, v3_); ADD(4, v4_); ADD(5, v5);
+    }
+#undef ADD
+    return pixel_disagrees;
+}
+
+/* Tie bounds of the gradients (file header): all `real`, each either NULL or sized like the gradient of the same name. */
+typedef struct {
+    real *means2D /* [P,3] */, *opacities /* [P] */, *colors /* [P,3] */, *semantics /* [P,K] */, *means3D /* [P,3] */,
+        *cov3D /* [P,6] */, *shs /* [P,M,3] */, *scales /* [P,3] */, *rotations /* [P,4] */;
+    long tie_pixels, tie_decisions, overflow_pixels;   /* out: what was evaluated */
+} HsroBounds;
+
+static void bound_add(real* arr, size_t i, real v)
+{
+    if (!arr) return;
+    v = R_FABS(v);
+    if (v == 0) return;
+#pragma omp atomic
+    arr[i] += v;
+}
+
+/* |J_id * delta| into the bound arrays: delta = a per-splat difference of the NA accumulated sums */
+static void bounds_add_delta(const HsroChain* ch, HsroBounds* b, uint32_t id, const double* delta, int K, int M, int inf)
+{
+    const HsroState* s = ch->s;
+    real in[9] = {(real)delta[0], (real)delta[1], (real)delta[2], (real)delta[3], (real)delta[4], (real)delta[9],
+                  (real)delta[6], (real)delta[7], (real)delta[8]};
+    real dm[3], dc[6], dsx[3], dr[4];
+    real* dsh = (ch->shs && M > 0) ? (real*)calloc((size_t)M * 3, sizeof(real)) : 0;
+    gauss_chain(ch, (int)id, in, dm, dc, ch->scales ? dsx : 0, ch->scales ? dr : 0, dsh);
+    const real big = inf ? (real)INFINITY : 0;
+    bound_add(b->means2D, 3 * (size_t)id, inf ? big : (real)delta[0]); bound_add(b->means2D, 3 * (size_t)id + 1, inf ? big : (real)delta[1]);
+    bound_add(b->opacities, id, inf ? big : (real)delta[5]);
+    if (!s->has_sh) for (int k = 0; k < 3; k++) bound_add(b->colors, 3 * (size_t)id + k, inf ? big : (real)delta[6 + k]);
+    for (int k = 0; k < K; k++) bound_add(b->semantics, (size_t)id * K + k, inf ? big : (real)delta[10 + k]);
+    for (int k = 0; k < 3; k++) bound_add(b->means3D, 3 * (size_t)id + k, inf ? big : dm[k]);
+    for (int k = 0; k < 6; k++) bound_add(b->cov3D, 6 * (size_t)id + k, inf ? big : dc[k]);
+    if (ch->scales) {
+        for (int k = 0; k < 3; k++) bound_add(b->scales, 3 * (size_t)id + k, inf ? big : dsx[k]);
+        for (int k = 0; k < 4; k++) bound_add(b->rotations, 4 * (size_t)id + k, inf ? big : dr[k]);
+    }
+    if (dsh) { for (int k = 0; k < 3 * M; k++) bound_add(b->shs, (size_t)id * M * 3 + k, inf ? big : dsh[k]); free(dsh); }
 }
 
 /*
  * Backward.  Follows Rasterizer::backward (rasterizer_impl.cu:349-454) / backward_semantic
  * (:614-731) according to how the state was produced.  Gradient outputs must be caller-allocated
- * and are fully overwritten (the reference zero-fills them first, rasterize_points.cu:378-388).
+ * and are fully overwritten (the reference zero-fills them first, rasterize_points.cu:378-388); they are `real`.
  * dL_dconic is [P,4] (only [0],[1],[3] written, backward.cu:658-660).  dL_dmean2D is [P,3].
  * sem_alpha_mode 0 = reference-as-observed: the semantic->alpha term reads a scratch buffer the
  * reference never writes (backward.cu:834, rasterizer_impl.cu:673-674), i.e. zeros.
+ * bounds (may be NULL): the tie bounds of the gradients, arrays zero-filled by the caller.
  */
 int hsro_backward(const HsroState* s, int D, int M, const float* background, const float* means3D, const float* shs,
                   const float* colors_precomp, const float* semantics, const float* scales, float scale_modifier,
                   const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                   const float* campos, float tan_fovx, float tan_fovy, const float* dL_dpix, const float* dL_dpix_sem,
                   const float* dL_dpix_depth, const float* dL_dpix_median, const float* dL_dpix_opacity,
-                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantics,
-                  float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                  int sem_alpha_mode)
+                  real* dL_dmean2D, real* dL_dconic, real* dL_dopacity, real* dL_dcolor, real* dL_dsemantics,
+                  real* dL_ddepth, real* dL_dmean3D, real* dL_dcov3D, real* dL_dsh, real* dL_dscale, real* dL_drot,
+                  int sem_alpha_mode, HsroBounds* bounds)
 {
-    (void)semantics;
     if (sem_alpha_mode != 0) return -1;
     const int P = s->P, W = s->W, H = s->H, K = s->semantic ? s->K : 0;
     const size_t N = (size_t)W * H;
@@ -596,252 +860,111 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
     size_t Pa = P ? (size_t)P : 1;
     double* acc = (double*)calloc(Pa * (size_t)NA, sizeof(double));
     if (!acc) return -2;
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H); /* backward.cu:550-551, :759-760 */
-    const int median_rule = g_median_rule;
+    HsroBwdCtx bc;
+    bc.s = s; bc.colors = colors; bc.background = background; bc.dL_dpix = dL_dpix; bc.dL_dpix_sem = dL_dpix_sem;
+    bc.dL_dpix_depth = dL_dpix_depth; bc.dL_dpix_median = dL_dpix_median; bc.dL_dpix_opacity = dL_dpix_opacity;
+    bc.N = N; bc.K = K; bc.NA = NA;
+    bc.ddelx_dx = (float)(0.5 * W); bc.ddely_dy = (float)(0.5 * H); /* backward.cu:550-551, :759-760 */
+    bc.median_rule = g_median_rule;
     long median_disagree = 0;
+    const HsroDecision no_ovr = {0, 0};
 
     /* ---- renderCUDA (backward.cu:472-666) / renderCUDA_SEM (backward.cu:669-899) ---- */
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : median_disagree)
     for (long tile = 0; tile < (long)Tn; tile++) {
         const uint32_t ty = (uint32_t)(tile / gx), tx = (uint32_t)(tile % gx);
         const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
-        float* dsem = (float*)malloc(sizeof(float) * (size_t)(K > 0 ? K : 1));
+        real* dsem = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
         for (int tyy = 0; tyy < BLOCK_Y; tyy++)
             for (int txx = 0; txx < BLOCK_X; txx++) {
                 uint32_t px = tx * BLOCK_X + txx, py = ty * BLOCK_Y + tyy;
                 if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
                 size_t pix_id = (size_t)W * py + px;
-                float pfx = (float)px, pfy = (float)py;
-                const float T_final = s->final_T[pix_id];
-                float T = T_final;
-                uint32_t contributor = r1 - r0;
-                const int last_contributor = (int)s->n_contrib[pix_id];
-                float accum_rec[NUM_CHANNELS] = {0, 0, 0}, dpx[NUM_CHANNELS], last_color[NUM_CHANNELS] = {0, 0, 0};
-                for (int c = 0; c < NUM_CHANNELS; c++) dpx[c] = dL_dpix[(size_t)c * N + pix_id];
-                const float dpd = dL_dpix_depth[pix_id], dpm = dL_dpix_median[pix_id], dpo = dL_dpix_opacity[pix_id];
-                for (int c = 0; c < K; c++) dsem[c] = dL_dpix_sem[(size_t)c * N + pix_id];
-                float accum_depth_rec = 0, accum_op_rec = 0, last_alpha = 0, last_depth = 0, last_op = 0;
-                const uint32_t median_at = s->median_pos[pix_id];
-                int pixel_disagrees = 0;
-                for (uint32_t ii = r1; ii > r0; ii--) { /* back to front, backward.cu:562, :771 */
-                    contributor--;
-                    if ((int64_t)contributor >= (int64_t)last_contributor) continue;
-                    uint32_t id = s->vals[ii - 1];
-                    float dx = s->means2D[2 * id] - pfx, dy = s->means2D[2 * id + 1] - pfy;
-                    const float* co = s->conic_opacity + 4 * (size_t)id;
-                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > 0.0f) continue;
-                    const float G = expf(power);
-                    const float alpha = fminf_(0.99f, co[3] * G);
-                    if (alpha < 1.0f / 255.0f) continue;
-                    float test_T = T / (1.f - alpha);
-                    const float w = alpha * test_T;
-                    double* a = acc + (size_t)id * NA;
-                    float dL_dalpha = 0.0f;
-                    for (int ch = 0; ch < NUM_CHANNELS; ch++) {
-                        const float c = colors[(size_t)id * NUM_CHANNELS + ch];
-                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                        last_color[ch] = c;
-                        dL_dalpha += (c - accum_rec[ch]) * dpx[ch];
-                        float v = w * dpx[ch];
-#pragma omp atomic
-                        a[6 + ch] += (double)v;
-                    }
-                    /* semantic: s == 0 (unwritten scratch), accum_rec_sem and last_semantic stay 0, so the
-                       dL_dalpha term (backward.cu:840) is exactly 0; only dL_dsemantics accumulates (:845) */
-                    for (int ch = 0; ch < K; ch++) {
-                        float v = w * dsem[ch];
-#pragma omp atomic
-                        a[10 + ch] += (double)v;
-                    }
-                    const float c_d = s->depths[id];
-                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                    last_depth = c_d;
-                    dL_dalpha += (c_d - accum_depth_rec) * dpd;
-                    {
-                        float v = w * dpd;
-#pragma omp atomic
-                        a[9] += (double)v;
-                    }
-                    {
-                        const int by_reference_rule = (test_T > 0.5f && T < 0.5); /* backward.cu:623-626, :854-857 */
-                        const int by_forward_record = (contributor + 1 == median_at);
-                        if (by_reference_rule != by_forward_record) pixel_disagrees = 1;
-                        if (median_rule ? by_forward_record : by_reference_rule) {
-#pragma omp atomic
-                            a[9] += (double)dpm;
-                        }
-                    }
-                    accum_op_rec = last_alpha * last_op + (1.f - last_alpha) * accum_op_rec;
-                    last_op = 1.f;
-                    dL_dalpha += (1.f - accum_op_rec) * dpo;
-                    {
-                        float v = w * dpo;
-#pragma omp atomic
-                        a[5] += (double)v;
-                    }
-                    dL_dalpha *= test_T;
-                    T = test_T;
-                    last_alpha = alpha;
-                    float bg_dot = 0;
-                    for (int i = 0; i < NUM_CHANNELS; i++) bg_dot += background[i] * dpx[i];
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                    const float dL_dG = co[3] * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * co[0] - gdy * co[1];
-                    const float dG_ddely = -gdy * co[2] - gdx * co[1];
-                    float v0 = dL_dG * dG_ddelx * ddelx_dx, v1 = dL_dG * dG_ddely * ddely_dy;
-                    float v2 = -0.5f * gdx * dx * dL_dG, v3_ = -0.5f * gdx * dy * dL_dG, v4_ = -0.5f * gdy * dy * dL_dG;
-                    float v5 = G * dL_dalpha;
-#pragma omp atomic
-                    a[0] += (double)v0;
-#pragma omp atomic
-                    a[1] += (double)v1;
-#pragma omp atomic
-                    a[2] += (double)v2;
-#pragma omp atomic
-                    a[3] += (double)v3_;
-#pragma omp atomic
-                    a[4] += (double)v4_;
-#pragma omp atomic
-                    a[5] += (double)v5;
-                }
-                median_disagree += pixel_disagrees;
+                median_disagree += pixel_backward(&bc, pix_id, (float)px, (float)py, r0, r1, s->final_T[pix_id], (int)s->n_contrib[pix_id],
+                                                  s->median_pos[pix_id], no_ovr, dsem, acc, 0);
             }
         free(dsem);
     }
     g_median_disagree = median_disagree;
     for (int i = 0; i < P; i++) {
         const double* a = acc + (size_t)i * NA;
-        dL_dmean2D[3 * i] = (float)a[0]; dL_dmean2D[3 * i + 1] = (float)a[1]; dL_dmean2D[3 * i + 2] = 0.f;
-        dL_dconic[4 * i] = (float)a[2]; dL_dconic[4 * i + 1] = (float)a[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = (float)a[4];
-        dL_dopacity[i] = (float)a[5];
-        for (int c = 0; c < 3; c++) dL_dcolor[3 * i + c] = (float)a[6 + c];
-        dL_ddepth[i] = (float)a[9];
-        for (int c = 0; c < K; c++) dL_dsemantics[(size_t)i * K + c] = (float)a[10 + c];
+        dL_dmean2D[3 * i] = (real)a[0]; dL_dmean2D[3 * i + 1] = (real)a[1]; dL_dmean2D[3 * i + 2] = 0.f;
+        dL_dconic[4 * i] = (real)a[2]; dL_dconic[4 * i + 1] = (real)a[3]; dL_dconic[4 * i + 2] = 0.f; dL_dconic[4 * i + 3] = (real)a[4];
+        dL_dopacity[i] = (real)a[5];
+        for (int c = 0; c < 3; c++) dL_dcolor[3 * i + c] = (real)a[6 + c];
+        dL_ddepth[i] = (real)a[9];
+        for (int c = 0; c < K; c++) dL_dsemantics[(size_t)i * K + c] = (real)a[10 + c];
     }
     free(acc);
 
-    memset(dL_dmean3D, 0, sizeof(float) * 3 * (size_t)P);
-    memset(dL_dcov3D, 0, sizeof(float) * 6 * (size_t)P);
-    if (dL_dscale) memset(dL_dscale, 0, sizeof(float) * 3 * (size_t)P);
-    if (dL_drot) memset(dL_drot, 0, sizeof(float) * 4 * (size_t)P);
-    if (dL_dsh && M > 0) memset(dL_dsh, 0, sizeof(float) * 3 * (size_t)M * (size_t)P);
-    const float* cov3Ds = cov3D_precomp ? cov3D_precomp : s->cov3D;
+    memset(dL_dmean3D, 0, sizeof(real) * 3 * (size_t)P);
+    memset(dL_dcov3D, 0, sizeof(real) * 6 * (size_t)P);
+    if (dL_dscale) memset(dL_dscale, 0, sizeof(real) * 3 * (size_t)P);
+    if (dL_drot) memset(dL_drot, 0, sizeof(real) * 4 * (size_t)P);
+    if (dL_dsh && M > 0) memset(dL_dsh, 0, sizeof(real) * 3 * (size_t)M * (size_t)P);
 
-    /* ---- computeCov2DCUDA, backward.cu:144-274 ---- */
+    HsroChain ch;
+    ch.s = s; ch.D = D; ch.M = M; ch.means3D = means3D; ch.shs = shs; ch.scales = scales; ch.rotations = rotations;
+    ch.cov3Ds = cov3D_precomp ? cov3D_precomp : s->cov3D; ch.viewmatrix = viewmatrix; ch.projmatrix = projmatrix; ch.campos = campos;
+    ch.scale_modifier = scale_modifier; ch.focal_x = focal_x; ch.focal_y = focal_y; ch.tan_fovx = tan_fovx; ch.tan_fovy = tan_fovy;
+
+    /* ---- computeCov2DCUDA (backward.cu:144-274) + preprocessCUDA (backward.cu:346-412), per Gaussian ---- */
 #pragma omp parallel for schedule(static)
     for (int idx = 0; idx < P; idx++) {
         if (!(s->radii[idx] > 0)) continue;
-        const float* cov3D = cov3Ds + 6 * (size_t)idx;
-        v3 mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-        const float dcx = dL_dconic[4 * idx], dcy = dL_dconic[4 * idx + 1], dcz = dL_dconic[4 * idx + 3];
-        v3 t; float txtz, tytz; m3 T, Vrk, c2;
-        cov2d_core(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &t, &txtz, &tytz, &T, &Vrk, &c2);
-        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-        float a = c2.c[0][0] + 0.3f, b = c2.c[0][1], c = c2.c[1][1] + 0.3f;
-        float denom = a * c - b * b;
-        float dL_da = 0, dL_db = 0, dL_dc = 0;
-        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        float* dcov = dL_dcov3D + 6 * (size_t)idx;
-#define TT(i, j) T.c[i][j]
-#define VV(i, j) Vrk.c[i][j]
-        if (denom2inv != 0) {
-            dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
-            dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
-            dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
-            dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
-            dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
-            dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
-            dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
-            dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
-            dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
-        } else {
-            for (int i = 0; i < 6; i++) dcov[i] = 0;
-        }
-        float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
-                        (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
-        float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
-                        (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
-        float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
-                        (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
-        float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
-                        (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
-        float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
-                        (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
-        float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
-                        (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
-#undef TT
-#undef VV
-        /* W as built at backward.cu:182-185: W[c][r] */
-        const float* vm = viewmatrix;
-        m3 Wm = m3_make(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
-        float dL_dJ00 = Wm.c[0][0] * dL_dT00 + Wm.c[0][1] * dL_dT01 + Wm.c[0][2] * dL_dT02;
-        float dL_dJ02 = Wm.c[2][0] * dL_dT00 + Wm.c[2][1] * dL_dT01 + Wm.c[2][2] * dL_dT02;
-        float dL_dJ11 = Wm.c[1][0] * dL_dT10 + Wm.c[1][1] * dL_dT11 + Wm.c[1][2] * dL_dT12;
-        float dL_dJ12 = Wm.c[2][0] * dL_dT10 + Wm.c[2][1] * dL_dT11 + Wm.c[2][2] * dL_dT12;
-        float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
-        const float h_x = focal_x, h_y = focal_y;
-        float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-        float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-        float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
-        v3 dt = {dL_dtx, dL_dty, dL_dtz};
-        v3 dm = transformVec4x3Transpose(dt, viewmatrix);
-        dL_dmean3D[3 * idx] = dm.x; dL_dmean3D[3 * idx + 1] = dm.y; dL_dmean3D[3 * idx + 2] = dm.z; /* assignment, :273 */
+        const real in[9] = {dL_dmean2D[3 * idx], dL_dmean2D[3 * idx + 1], dL_dconic[4 * idx], dL_dconic[4 * idx + 1], dL_dconic[4 * idx + 3],
+                            dL_ddepth[idx], dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2]};
+        gauss_chain(&ch, idx, in, dL_dmean3D + 3 * (size_t)idx, dL_dcov3D + 6 * (size_t)idx, scales ? dL_dscale + 3 * (size_t)idx : 0,
+                    scales ? dL_drot + 4 * (size_t)idx : 0, (shs && dL_dsh) ? dL_dsh + (size_t)idx * M * 3 : 0);
     }
 
-    /* ---- preprocessCUDA (backward), backward.cu:346-412 (also the semantic path, :1117) ---- */
-#pragma omp parallel for schedule(static)
-    for (int idx = 0; idx < P; idx++) {
-        if (!(s->radii[idx] > 0)) continue;
-        v3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-        const float* proj = projmatrix; const float* view = viewmatrix;
-        v4 m_hom = transformPoint4x4(m, proj);
-        float m_w = 1.0f / (m_hom.w + 0.0000001f);
-        float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
-        float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
-        const float d2x = dL_dmean2D[3 * idx], d2y = dL_dmean2D[3 * idx + 1];
-        float gxm = (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
-        float gym = (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
-        float gzm = (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
-        dL_dmean3D[3 * idx] += gxm; dL_dmean3D[3 * idx + 1] += gym; dL_dmean3D[3 * idx + 2] += gzm;
-        float mul3 = view[2] * m.x + view[6] * m.y + view[10] * m.z + view[14];
-        const float dd = dL_ddepth[idx];
-        dL_dmean3D[3 * idx] += (view[2] - view[3] * mul3) * dd;
-        dL_dmean3D[3 * idx + 1] += (view[6] - view[7] * mul3) * dd;
-        dL_dmean3D[3 * idx + 2] += (view[10] - view[11] * mul3) * dd;
-        if (shs) computeColorFromSH_bwd(idx, D, M, means3D, campos, shs, s->clamped, dL_dcolor, dL_dmean3D, dL_dsh);
-        if (scales) {
-            /* computeCov3D backward, backward.cu:278-341 */
-            float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
-            m3 Rm = m3_make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
-                            2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
-                            2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
-            m3 S = m3_make(1, 0, 0, 0, 1, 0, 0, 0, 1);
-            float sx = scale_modifier * scales[3 * idx], sy = scale_modifier * scales[3 * idx + 1], sz = scale_modifier * scales[3 * idx + 2];
-            S.c[0][0] = sx; S.c[1][1] = sy; S.c[2][2] = sz;
-            m3 Mm = m3_mul(&S, &Rm);
-            const float* dc = dL_dcov3D + 6 * (size_t)idx;
-            m3 dSig = m3_make(dc[0], 0.5f * dc[1], 0.5f * dc[2], 0.5f * dc[1], dc[3], 0.5f * dc[4], 0.5f * dc[2], 0.5f * dc[4], dc[5]);
-            m3 M2 = Mm;
-            for (int cc = 0; cc < 3; cc++) for (int rr = 0; rr < 3; rr++) M2.c[cc][rr] = 2.0f * Mm.c[cc][rr]; /* 2.0f * M */
-            m3 dL_dM = m3_mul(&M2, &dSig);
-            m3 Rt = m3_transpose(&Rm);
-            m3 dMt = m3_transpose(&dL_dM);
-            dL_dscale[3 * idx] = Rt.c[0][0] * dMt.c[0][0] + Rt.c[0][1] * dMt.c[0][1] + Rt.c[0][2] * dMt.c[0][2];
-            dL_dscale[3 * idx + 1] = Rt.c[1][0] * dMt.c[1][0] + Rt.c[1][1] * dMt.c[1][1] + Rt.c[1][2] * dMt.c[1][2];
-            dL_dscale[3 * idx + 2] = Rt.c[2][0] * dMt.c[2][0] + Rt.c[2][1] * dMt.c[2][1] + Rt.c[2][2] * dMt.c[2][2];
-            for (int k = 0; k < 3; k++) { dMt.c[0][k] *= sx; dMt.c[1][k] *= sy; dMt.c[2][k] *= sz; }
-#define DM(i, j) dMt.c[i][j]
-            float qx = 2 * z * (DM(0, 1) - DM(1, 0)) + 2 * y * (DM(2, 0) - DM(0, 2)) + 2 * x * (DM(1, 2) - DM(2, 1));
-            float qy = 2 * y * (DM(1, 0) + DM(0, 1)) + 2 * z * (DM(2, 0) + DM(0, 2)) + 2 * r * (DM(1, 2) - DM(2, 1)) - 4 * x * (DM(2, 2) + DM(1, 1));
-            float qz = 2 * x * (DM(1, 0) + DM(0, 1)) + 2 * r * (DM(2, 0) - DM(0, 2)) + 2 * z * (DM(1, 2) + DM(2, 1)) - 4 * y * (DM(2, 2) + DM(0, 0));
-            float qw = 2 * r * (DM(0, 1) - DM(1, 0)) + 2 * x * (DM(2, 0) + DM(0, 2)) + 2 * y * (DM(1, 2) + DM(2, 1)) - 4 * z * (DM(1, 1) + DM(0, 0));
-#undef DM
-            dL_drot[4 * idx] = qx; dL_drot[4 * idx + 1] = qy; dL_drot[4 * idx + 2] = qz; dL_drot[4 * idx + 3] = qw;
+    /* ---- tie bounds of the gradients: every flagged decision of every flagged pixel taken the other way ---- */
+    if (bounds) {
+        long n_pix = 0, n_dec = 0, n_ovf = 0;
+        const float* feat = colors;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : n_pix, n_dec, n_ovf)
+        for (long pix = 0; pix < (long)N; pix++) {
+            if (!s->tie_pixels[pix]) continue;
+            const uint32_t px = (uint32_t)(pix % W), py = (uint32_t)(pix / W);
+            const size_t tile = (size_t)(py / BLOCK_Y) * gx + px / BLOCK_X;
+            const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+            const size_t nl = (size_t)(r1 - r0);
+            real* Sacc = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
+            real* dsem = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
+            double* base = (double*)calloc((nl ? nl : 1) * (size_t)NA, sizeof(double));
+            double* alt = (double*)malloc((nl ? nl : 1) * (size_t)NA * sizeof(double));
+            HsroPixFwd f;
+            pixel_forward(s, feat, semantics, K, r0, r1, (float)px, (float)py, no_ovr, 1, Sacc, &f);
+            pixel_backward(&bc, (size_t)pix, (float)px, (float)py, r0, r1, f.T, (int)f.last_contributor, f.median_at, no_ovr, dsem, 0, base);
+            n_pix++; n_dec += f.ndec; n_ovf += f.overflow;
+            for (int d = 0; d < f.ndec; d++) {
+                if (f.dec[d].kind == 4) {
+                    /* T passed within ulps of 0.5 here: dL_dmedian_depth may go to this splat or not */
+                    double* dl = (double*)calloc((size_t)NA, sizeof(double));
+                    dl[9] = (double)dL_dpix_median[pix];
+                    bounds_add_delta(&ch, bounds, s->vals[f.dec[d].pos], dl, K, M, 0);
+                    free(dl);
+                    continue;
+                }
+                HsroPixFwd g;
+                pixel_forward(s, feat, semantics, K, r0, r1, (float)px, (float)py, f.dec[d], 0, Sacc, &g);
+                memset(alt, 0, (nl ? nl : 1) * (size_t)NA * sizeof(double));
+                pixel_backward(&bc, (size_t)pix, (float)px, (float)py, r0, r1, g.T, (int)g.last_contributor, g.median_at, f.dec[d], dsem, 0, alt);
+                for (size_t j = 0; j < nl; j++) {
+                    double* da = alt + j * NA; const double* ba = base + j * NA;
+                    int any = 0;
+                    for (int k = 0; k < NA; k++) { da[k] -= ba[k]; any |= (da[k] != 0.0); }
+                    if (any) bounds_add_delta(&ch, bounds, s->vals[r0 + j], da, K, M, 0);
+                }
+            }
+            if (f.overflow) {   /* more flagged decisions than tracked: no bound for the splats of this pixel */
+                double* dl = (double*)calloc((size_t)NA, sizeof(double));
+                for (uint32_t i = r0; i < f.i_end; i++) bounds_add_delta(&ch, bounds, s->vals[i], dl, K, M, 1);
+                free(dl);
+            }
+            free(Sacc); free(dsem); free(base); free(alt);
         }
+        bounds->tie_pixels = n_pix; bounds->tie_decisions = n_dec; bounds->overflow_pixels = n_ovf;
     }
     return 0;
 }

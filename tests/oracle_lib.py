@@ -10,36 +10,49 @@ import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "libhsr_oracle.so")
-_lib = None
+_SO64 = os.path.join(_ROOT, "oracle", "libhsr_oracle_f64.so")   # the "truth" build: same fp32 lists, arithmetic in double
+_libs = {}
 
 FIELDS = dict(depths=0, means2D=1, conic_opacity=2, cov3D=3, rgb=4, clamped=5, radii=6, tiles_touched=7,
               point_offsets=8, keys_unsorted=9, keys=10, vals_unsorted=11, vals=12, ranges=13, final_T=14, n_contrib=15,
-              median_pos=16, tie_pixels=17, tie_gaussians=18)
+              median_pos=16, tie_pixels=17, tie_gaussians=18, tie_img_bound=19)
+IMG_BOUND_PLANES = ("color", "depth", "opacity", "semantic", "final_T", "mask")   # tie_img_bound[plane][pixel]
 
 
-def build(force=False):
-    src = os.path.join(_ROOT, "oracle", "hsr_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-B", "libhsr_oracle.so"],
+def build(force=False, precision="f32"):
+    so = _SO64 if precision == "f64" else _SO
+    srcs = [os.path.join(_ROOT, "oracle", n) for n in ("hsr_oracle.c", "hsr_oracle_la.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-B", os.path.basename(so)],
                               stdout=subprocess.DEVNULL)
-    return _SO
+    return so
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
-        _lib.hsro_forward.restype = C.c_void_p
-        _lib.hsro_field.restype = C.c_void_p
-        _lib.hsro_field.argtypes = [C.c_void_p, C.c_int]
-        _lib.hsro_num_rendered.argtypes = [C.c_void_p]
-        _lib.hsro_free.argtypes = [C.c_void_p]
-        _lib.hsro_get_higher_msb.restype = C.c_uint32
-        _lib.hsro_get_higher_msb.argtypes = [C.c_uint32]
-        _lib.hsro_set_median_rule.argtypes = [C.c_int]
-        _lib.hsro_last_median_rule_disagreements.restype = C.c_long
-    return _lib
+class Bounds(C.Structure):
+    """HsroBounds (oracle/hsr_oracle.c): tie bounds of the gradients, caller-allocated arrays of `real`"""
+    _fields_ = [(n, C.c_void_p) for n in ("means2D", "opacities", "colors", "semantics", "means3D", "cov3D", "shs", "scales",
+                                          "rotations")] + [("tie_pixels", C.c_long), ("tie_decisions", C.c_long),
+                                                           ("overflow_pixels", C.c_long)]
+
+
+def lib(precision="f32"):
+    """precision "f32": the oracle; "f64": the truth build (images, final_T and gradients come back as float64)"""
+    L = _libs.get(precision)
+    if L is None:
+        L = C.CDLL(build(precision=precision))
+        L.hsro_forward.restype = C.c_void_p
+        L.hsro_field.restype = C.c_void_p
+        L.hsro_field.argtypes = [C.c_void_p, C.c_int]
+        L.hsro_num_rendered.argtypes = [C.c_void_p]
+        L.hsro_free.argtypes = [C.c_void_p]
+        L.hsro_get_higher_msb.restype = C.c_uint32
+        L.hsro_get_higher_msb.argtypes = [C.c_uint32]
+        L.hsro_set_median_rule.argtypes = [C.c_int]
+        L.hsro_last_median_rule_disagreements.restype = C.c_long
+        assert L.hsro_real_bytes() == (8 if precision == "f64" else 4)
+        L.real = np.float64 if precision == "f64" else np.float32
+        _libs[precision] = L
+    return L
 
 
 def _f(a):
@@ -60,12 +73,13 @@ def _np(x):
 
 
 class OracleState:
-    def __init__(self, handle, P, W, H, K, R, keep):
+    def __init__(self, handle, P, W, H, K, R, keep, precision="f32"):
         self.h, self.P, self.W, self.H, self.K, self.R = handle, P, W, H, K, R
         self._keep = keep
+        self.precision = precision
 
     def field(self, name):
-        L = lib()
+        L = lib(self.precision)
         p = L.hsro_field(C.c_void_p(self.h), FIELDS[name])
         P, R, N = self.P, self.R, self.W * self.H
         T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
@@ -73,18 +87,22 @@ class OracleState:
                     cov3D=(np.float32, (P, 6)), rgb=(np.float32, (P, 3)), clamped=(np.uint8, (P, 3)),
                     radii=(np.int32, (P,)), tiles_touched=(np.uint32, (P,)), point_offsets=(np.uint32, (P,)),
                     keys_unsorted=(np.uint64, (R,)), keys=(np.uint64, (R,)), vals_unsorted=(np.uint32, (R,)),
-                    vals=(np.uint32, (R,)), ranges=(np.uint32, (T, 2)), final_T=(np.float32, (N,)),
+                    vals=(np.uint32, (R,)), ranges=(np.uint32, (T, 2)), final_T=(L.real, (N,)),
                     n_contrib=(np.uint32, (N,)), median_pos=(np.uint32, (N,)), tie_pixels=(np.uint8, (N,)),
-                    tie_gaussians=(np.uint8, (P,)))[name]
+                    tie_gaussians=(np.uint8, (P,)), tie_img_bound=(L.real, (len(IMG_BOUND_PLANES), N)))[name]
         n = int(np.prod(spec[1]))
         if n == 0:
             return np.zeros(spec[1], dtype=spec[0])
         buf = (C.c_char * (n * np.dtype(spec[0]).itemsize)).from_address(p)
         return np.frombuffer(buf, dtype=spec[0]).reshape(spec[1]).copy()
 
+    def img_bound(self, name):
+        """how far the output `name` of each pixel moves when its flagged threshold decisions go the other way ([N]; 0 elsewhere)"""
+        return self.field("tie_img_bound")[IMG_BOUND_PLANES.index(name)]
+
     def free(self):
         if self.h:
-            lib().hsro_free(C.c_void_p(self.h))
+            lib(self.precision).hsro_free(C.c_void_p(self.h))
             self.h = None
 
     def __del__(self):
@@ -95,10 +113,12 @@ class OracleState:
 
 
 def forward(cam, means3D, opacities, colors_precomp=None, shs=None, semantics_precomp=None, scales=None,
-            rotations=None, cov3D_precomp=None, threads=0):
+            rotations=None, cov3D_precomp=None, threads=0, precision="f32"):
     """Oracle forward.  `cam` is a dict / NamedTuple with the GaussianRasterizationSettings fields.
-    Returns (outputs dict, OracleState).  Semantic variant iff semantics_precomp is not None."""
-    L = lib()
+    Returns (outputs dict, OracleState).  Semantic variant iff semantics_precomp is not None.
+    precision "f64": the truth build (float64 images; identical integer state)."""
+    L = lib(precision)
+    rt = L.real
     if threads:
         L.hsro_set_threads(C.c_int(threads))
     g = (lambda k: cam[k]) if isinstance(cam, dict) else (lambda k: getattr(cam, k))
@@ -112,12 +132,12 @@ def forward(cam, means3D, opacities, colors_precomp=None, shs=None, semantics_pr
     semantic = sem_np is not None
     K = sem_np.shape[1] if semantic else 0
     N = W * H
-    out_color = np.zeros((3, H, W), np.float32)
-    out_sem = np.zeros((K, H, W), np.float32)
-    out_depth = np.zeros((1, H, W), np.float32)
-    out_median = np.zeros((1, H, W), np.float32)
-    out_op = np.zeros((1, H, W), np.float32)
-    out_mask = np.zeros((1, H, W), np.float32)
+    out_color = np.zeros((3, H, W), rt)
+    out_sem = np.zeros((K, H, W), rt)
+    out_depth = np.zeros((1, H, W), rt)
+    out_median = np.zeros((1, H, W), rt)
+    out_op = np.zeros((1, H, W), rt)
+    out_mask = np.zeros((1, H, W), rt)
     radii = np.zeros((P,), np.int32)
     keep = []
     def f(a):
@@ -138,7 +158,7 @@ def forward(cam, means3D, opacities, colors_precomp=None, shs=None, semantics_pr
     if not h:
         raise MemoryError("hsro_forward failed")
     R = L.hsro_num_rendered(C.c_void_p(h))
-    st = OracleState(h, P, W, H, K, R, keep)
+    st = OracleState(h, P, W, H, K, R, keep, precision)
     out = dict(num_rendered=R, color=out_color, depth=out_depth, median_depth=out_median, opacity=out_op, radii=radii)
     if semantic:
         out["semantic"] = out_sem
@@ -148,13 +168,16 @@ def forward(cam, means3D, opacities, colors_precomp=None, shs=None, semantics_pr
 
 
 def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_precomp=None, scales=None,
-             rotations=None, cov3D_precomp=None, threads=0, median_rule="reference"):
+             rotations=None, cov3D_precomp=None, threads=0, median_rule="reference", bounds=False):
     """Oracle backward.  grads: dict(color[3,H,W], semantic[K,H,W]|None, depth, median, opacity).
     median_rule: "reference" = the splat the backward re-finds from its reconstructed T (backward.cu:623-626, :854-857);
     "forward" = the splat whose list position the forward recorded (what the HIP product does; identical except where the
     reconstructed T passes within rounding of 0.5).  The result carries `median_rule_disagreements`: the number of pixels on
-    which the two rules pick differently."""
-    L = lib()
+    which the two rules pick differently.
+    bounds=True: also the tie bounds of the gradients (oracle/hsr_oracle.c, "Threshold ties") as o["bounds"][name] — how far
+    each gradient entry moves when the flagged threshold decisions of the flagged pixels are taken the other way."""
+    L = lib(st.precision)
+    rt = L.real
     L.hsro_set_median_rule(C.c_int({"reference": 0, "forward": 1}[median_rule]))
     if threads:
         L.hsro_set_threads(C.c_int(threads))
@@ -168,14 +191,24 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
         arr, p = _f(_np(a))
         keep.append(arr)
         return p
-    o = dict(means2D=np.zeros((P, 3), np.float32), conic=np.zeros((P, 4), np.float32), opacities=np.zeros((P, 1), np.float32),
-             colors_precomp=np.zeros((P, 3), np.float32), semantics_precomp=np.zeros((P, K), np.float32),
-             depths=np.zeros((P, 1), np.float32), means3D=np.zeros((P, 3), np.float32), cov3D_precomp=np.zeros((P, 6), np.float32),
-             shs=np.zeros((P, M, 3), np.float32), scales=np.zeros((P, 3), np.float32), rotations=np.zeros((P, 4), np.float32))
+    o = dict(means2D=np.zeros((P, 3), rt), conic=np.zeros((P, 4), rt), opacities=np.zeros((P, 1), rt),
+             colors_precomp=np.zeros((P, 3), rt), semantics_precomp=np.zeros((P, K), rt),
+             depths=np.zeros((P, 1), rt), means3D=np.zeros((P, 3), rt), cov3D_precomp=np.zeros((P, 6), rt),
+             shs=np.zeros((P, M, 3), rt), scales=np.zeros((P, 3), rt), rotations=np.zeros((P, 4), rt))
     def po(name):
         a = o[name]
         return a.ctypes.data_as(C.c_void_p) if a.size else C.c_void_p(0)
     has_scales = scales is not None and _np(scales).size > 0
+    bstruct, barr = None, None
+    if bounds:
+        barr = dict(means2D=np.zeros((P, 3), rt), opacities=np.zeros((P, 1), rt), colors_precomp=np.zeros((P, 3), rt),
+                    semantics_precomp=np.zeros((P, K), rt), means3D=np.zeros((P, 3), rt), cov3D_precomp=np.zeros((P, 6), rt),
+                    shs=np.zeros((P, M, 3), rt), scales=np.zeros((P, 3), rt), rotations=np.zeros((P, 4), rt))
+        bstruct = Bounds()
+        for cname, pname in (("means2D", "means2D"), ("opacities", "opacities"), ("colors", "colors_precomp"),
+                             ("semantics", "semantics_precomp"), ("means3D", "means3D"), ("cov3D", "cov3D_precomp"), ("shs", "shs"),
+                             ("scales", "scales"), ("rotations", "rotations")):
+            setattr(bstruct, cname, barr[pname].ctypes.data if barr[pname].size else None)
     rc = L.hsro_backward(C.c_void_p(st.h), C.c_int(D), C.c_int(M), f(g("bg")), f(means3D), f(shs_np), f(colors_precomp),
                          f(semantics_precomp), f(scales), C.c_float(float(g("scale_modifier"))), f(rotations),
                          f(cov3D_precomp), f(g("viewmatrix")), f(g("projmatrix")), f(g("campos")),
@@ -184,9 +217,13 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
                          po("means2D"), po("conic"), po("opacities"), po("colors_precomp"), po("semantics_precomp"),
                          po("depths"), po("means3D"), po("cov3D_precomp"), po("shs"),
                          po("scales") if has_scales else C.c_void_p(0), po("rotations") if has_scales else C.c_void_p(0),
-                         C.c_int(0))
+                         C.c_int(0), C.byref(bstruct) if bstruct is not None else C.c_void_p(0))
     if rc != 0:
         raise RuntimeError("hsro_backward rc=%d" % rc)
+    if bounds:
+        o["bounds"] = barr
+        o["bounds_info"] = dict(tie_pixels=int(bstruct.tie_pixels), tie_decisions=int(bstruct.tie_decisions),
+                                overflow_pixels=int(bstruct.overflow_pixels))
     o["median_rule_disagreements"] = int(L.hsro_last_median_rule_disagreements())
     L.hsro_set_median_rule(C.c_int(0))
     return o

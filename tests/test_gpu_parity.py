@@ -42,7 +42,7 @@ CASES = {
 }
 
 
-TIE_MASKED = []   # comparisons that only passed outside the oracle's tie-risk set (reported at the end of the run: tests/conftest.py)
+TIE_BOUNDED = []   # comparisons that needed the oracle's tie bound (reported at the end of the run: tests/conftest.py)
 
 
 def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
@@ -68,30 +68,31 @@ def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
     mmis = int((st_g["median_pos"] != st_o.field("median_pos")).sum())   # the recorded T = 0.5 crossing: same kind of tie
     assert mmis <= max(2, npix // 2000), "median_pos mismatches: %d" % mmis
     # ---- images and gradients: strict first.  Where that fails, the oracle says which pixels took a decision within a few ulps of its
-    # threshold (alpha >= 1/255, T(1 - alpha) < 1e-4, power > 0, T crossing 0.5: oracle/hsr_oracle.c tie_pixels / tie_gaussians) — there
-    # v_exp_f32 and glibc's expf may decide differently and the pixel differs by a whole contribution.  Such a case passes if everything
-    # OUTSIDE the flagged pixels / the splats that contribute to them is within the bound, and the flagged set is small. ----
+    # threshold (alpha >= 1/255, T(1 - alpha) < 1e-4, power > 0, T crossing 0.5) — there v_exp_f32 and glibc's expf may decide
+    # differently and the pixel differs by a whole contribution — and HOW FAR each output / gradient entry moves when such a decision
+    # goes the other way (oracle/hsr_oracle.c "Threshold ties": every flagged decision evaluated both ways).  The comparison is then
+    # repeated with TIE_SLACK x that bound added entry by entry: nothing is left out, an error larger than one flipped decision
+    # explains still fails, and the rows whose allowance exceeds their ordinary bound are counted and capped. ----
     tie_pix = st_o.field("tie_pixels").astype(bool).reshape(-1)
-    tie_g = st_o.field("tie_gaussians").astype(bool).reshape(-1)
     assert int(tie_pix.sum()) <= max(8, npix // 200), "tie-risk pixels: %d of %d" % (int(tie_pix.sum()), npix)
+    assert st_o.bounds_info["overflow_pixels"] == 0, st_o.bounds_info
 
     def close(name, got, exp, per, **kw):
         try:
             assert_close(name, got, exp, **kw)
         except AssertionError:
-            mask = tie_pix if per == "pixel" else tie_g
-            if not mask.any():
-                raise
             import harness
-            harness.OBSERVED.pop()   # the strict attempt's record: replaced by the masked one below
-            got2 = np.array(got, np.float64, copy=True)
-            exp2 = np.asarray(exp, np.float64).reshape(got2.shape)
-            if per == "pixel":
-                got2.reshape(-1, npix)[:, mask] = exp2.reshape(-1, npix)[:, mask]
-            else:
-                got2.reshape(mask.size, -1)[mask] = exp2.reshape(mask.size, -1)[mask]
-            assert_close(name + " (outside the oracle's tie-risk set)", got2, exp2, **kw)
-            TIE_MASKED.append(name)
+            allowance = harness.tie_allowance(name, st_o, np.asarray(got).shape, per)
+            if not (allowance > 0).any():
+                raise
+            harness.OBSERVED.pop()   # the strict attempt's record: replaced by the bounded one below
+            assert_close(name + " (beyond the oracle's tie bound)", got, exp, allowance=allowance, **kw)
+            if per == "gauss":
+                loose = harness.loosened_rows(np.asarray(exp, np.float64).reshape(np.asarray(got).shape), allowance, harness.floor_for(name))
+                rows = np.asarray(got).shape[0]
+                assert loose <= max(harness.TIE_LOOSENED_MIN, int(harness.TIE_LOOSENED_FRAC * rows)), \
+                    "%s: %d of %d rows are loosened by the tie bound" % (name, loose, rows)
+            TIE_BOUNDED.append(name)
 
     names = ["color", "depth", "opacity"] + (["semantic"] if semantic else ["mask"])
     for n in names:

@@ -322,3 +322,88 @@ def test_scale_rotation_gradients_are_the_ill_conditioned_ones():
     others = max(v for n, v in worst.items() if n not in ("scales", "rotations"))
     assert max(worst["scales"], worst["rotations"]) > 2.0 * others
     assert max(worst["scales"], worst["rotations"]) > 2e-5        # > 20x amplification
+
+
+# ---- the truth build (libhsr_oracle_f64.so) and the tie bounds ------------------------------------------------------------
+
+@pytest.mark.parametrize("cfg", [(96, 64, 800, 26, "aniso", 2.0), (170, 112, 2500, 74, "aniso", 3.0), (69, 39, 300, 1, "aniso", 1.0),
+                                 (128, 80, 2000, 16, "slam", 3.0)])
+def test_truth_build_walks_the_same_lists_and_the_oracle_is_one_rounding_from_it(cfg):
+    """libhsr_oracle_f64.so runs the SAME fp32 preprocess / key / sort code (identical radii, keys, lists) and then the
+    compositing, its backward and the per-Gaussian chain in double.  The fp32 oracle must sit within a few fp32 roundings of
+    it everywhere — except where one of its threshold decisions fell within ulps of the threshold and the double evaluation
+    took it the other way: there the difference must be covered by the bound the oracle computed for exactly that entry."""
+    import harness
+    W, H, P, K, kind, sm = cfg
+    cam, sc, up = scenes.build(W, H, P, K, seed=11, kind=kind, scale_mult=sm)
+    o32, g32, s32 = run_oracle(cam, sc, up, semantic=True, threads=4)
+    o64, g64, s64 = run_oracle(cam, sc, up, semantic=True, threads=4, precision="f64", bounds=False)
+    assert o64["color"].dtype == np.float64 and g64["means3D"].dtype == np.float64
+    for n in ("radii",):
+        assert np.array_equal(o32[n], o64[n])
+    for n in ("keys", "vals", "ranges", "tiles_touched", "depths", "means2D", "conic_opacity"):
+        assert np.array_equal(s32.field(n), s64.field(n)), n
+    tie = s32.field("tie_pixels").astype(bool)
+    # thresholded integers may differ on flagged pixels only
+    assert not ((s32.field("n_contrib") != s64.field("n_contrib")) & ~tie).any()
+    for n in ("color", "depth", "opacity", "semantic"):
+        a = harness.tie_allowance(n, s32, o32[n].shape, "pixel")
+        d = np.maximum(np.abs(o32[n].astype(np.float64) - o64[n]) - a, 0.0)
+        assert d.max() <= 3e-6 * max(1.0, np.abs(o64[n]).max()), (n, d.max())
+    for n in g32:
+        t = np.asarray(g64[n], np.float64)
+        a = harness.tie_allowance("grad " + n, s32, t.shape, "gauss")
+        d = np.maximum(np.abs(np.asarray(g32[n], np.float64).reshape(t.shape) - t) - a, 0.0)
+        mx = float(np.abs(t).max())
+        assert d.max() <= 2e-5 * mx, (n, d.max() / mx)      # the cov chain amplifies one rounding ~50x (see the conditioning test)
+    s32.free(); s64.free()
+
+
+def test_tie_bound_covers_a_decision_forced_the_other_way():
+    """One splat centred exactly on a pixel centre with opacity exactly 1/255: its alpha on that pixel IS the threshold (power = 0,
+    exp = 1), so the oracle accepts it (alpha >= 1/255) and flags the decision.  Lowering the opacity by one ulp rejects it there:
+    the two renders differ on that pixel by the splat's whole contribution and in the gradient rows of everything behind and in
+    front of it.  The bound the first render computed must cover that difference, and must not be much larger than it."""
+    import harness
+    W, H, K, P = 48, 32, 5, 60
+    cam, sc, up = scenes.build(W, H, P, K, seed=21, kind="aniso", scale_mult=6.0, tilt=False)
+    # camera-centred splat j projected onto pixel (px, py): replica intrinsics scaled to W x H, w2c = I
+    from hsr_utils.camera import replica_intrinsics
+    k = replica_intrinsics(W, H)
+    px, py, z = 20, 13, 1.5
+    j = 7
+    # pixel = f * X / Z + c - 0.5 (ndc2Pix of the OpenGL-style projection, auxiliary.h:43)
+    sc["means3D"][j] = torch.tensor([(px + 0.5 - k[0, 2]) * z / k[0, 0], (py + 0.5 - k[1, 2]) * z / k[1, 1], z], dtype=torch.float32)
+    sc["opacities"][j] = float(np.float32(1.0) / np.float32(255.0))
+    outs = []
+    for nudge in (False, True):
+        s2 = {n: v.clone() for n, v in sc.items()}
+        if nudge:
+            s2["opacities"][j] = float(np.nextafter(np.float32(float(s2["opacities"][j])), np.float32(0)))
+        outs.append(run_oracle(cam, s2, up, semantic=True, threads=2))
+    (oa, ga, sa), (ob, gb, sb) = outs
+    pix = py * W + px
+    m2 = sa.field("means2D")[j]
+    if not (abs(m2[0] - px) < 1e-4 and abs(m2[1] - py) < 1e-4):
+        pytest.skip("projection did not land on the pixel centre: %s" % (m2,))
+    assert sa.field("tie_pixels")[pix] == 1 and sa.field("tie_gaussians")[j] == 1
+    moved = 0
+    for n in ("color", "depth", "opacity", "semantic"):
+        d = np.abs(oa[n].astype(np.float64) - ob[n]).reshape(oa[n].shape[0], -1)
+        b = sa.img_bound(n).astype(np.float64)
+        assert (d <= harness.TIE_SLACK * b[None, :] + 1e-6).all(), (n, float((d - b[None, :]).max()))
+        if d[:, pix].max() > 1e-5:
+            moved += 1
+            assert b[pix] <= 3.0 * d[:, pix].max() + 1e-6, (n, b[pix], d[:, pix].max())   # the bound is not vacuous
+    assert moved >= 3, "the flip did not happen"
+    for n in ga:
+        x, y = np.asarray(ga[n], np.float64), np.asarray(gb[n], np.float64).reshape(np.asarray(ga[n]).shape)
+        if x.size == 0:
+            continue
+        b = np.asarray(sa.grad_bounds[n], np.float64).reshape(x.shape)
+        mx = float(np.abs(x).max())
+        d = np.abs(x - y)
+        assert (d <= harness.TIE_SLACK * b + 2e-6 * mx).all(), (n, float((d - harness.TIE_SLACK * b).max() / mx))
+    # rows of splats that never touch the flagged pixel carry no bound at all
+    assert float(sa.grad_bounds["means3D"][~sa.field("tie_gaussians").astype(bool)].max(initial=0.0)) == 0.0
+    sa.free(); sb.free()

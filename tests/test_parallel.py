@@ -72,10 +72,86 @@ def _worker(rank, world, port, q):
     h = b.all_reduce(average=True, async_op=True)
     h.wait()
     assert torch.allclose(b.flat, torch.full((3,), sum(range(1, world + 1)) / world))
+    _exchange_checks(rank, world)
     if rank == 0:
         q.put([p.grad.numpy() for p in params])
     dist.barrier()
     dist.destroy_process_group()
+
+
+class _ToyRender(torch.autograd.Function):
+    """stands in for the rasterizer's autograd node on the CPU: its backward takes its gradient outputs from the gradient sink
+    exactly as diff_gaussian_rasterization/_C.py does (a fresh allocation when no sink is installed)"""
+
+    @staticmethod
+    def forward(ctx, a, b, c, ga, gb, gc):
+        ctx.save_for_backward(ga, gb, gc)
+        return (a * 0).sum() + (b * 0).sum() + (c * 0).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        from diff_gaussian_rasterization import _C
+        outs = []
+        for name, src in zip(("raster.means3D", "raster.semantics_precomp", "raster.opacities"), ctx.saved_tensors):
+            t = _C._from_sink(name, tuple(src.shape), src.device)
+            if t is None:
+                t = torch.empty_like(src)
+            t.copy_(src)                      # the kernel overwrites every row (zeros for the Gaussians it did not see)
+            outs.append(t)
+        return outs[0], outs[1], outs[2], None, None, None
+
+
+def _exchange_checks(rank, world):
+    """GradientExchange: the leaves' gradients ARE slices of the bucket after backward (nothing packed), and the visibility-sparse
+    exchange of partially overlapping views equals the dense all-reduce bit for bit (two ranks: a + b)."""
+    from hsr_utils.parallel import GradientExchange, allreduce_gradients
+    P = 200
+    gen = torch.Generator().manual_seed(100 + rank)
+    leaves = {"raster.means3D": torch.zeros(P, 3, requires_grad=True), "raster.semantics_precomp": torch.zeros(P, 5, requires_grad=True),
+              "raster.opacities": torch.zeros(P, 1, requires_grad=True)}
+    ex = GradientExchange(leaves, "cpu", depth=2, sparse=True, dense_above=0.9)
+    ref_leaves = [torch.zeros_like(t).requires_grad_(True) for t in leaves.values()]
+    views = {0: [(0, 120), (0, 200), (10, 60)], 1: [(80, 160), (0, 200), (50, 90)]}      # rows each rank sees, per step
+    expect_sparse = [True, False, True]                                                    # union 160 / 200 / 80 of 200 rows
+    kept = {}
+    for step in range(3):
+        lo, hi = views[rank][step]
+        radii = torch.zeros(P, dtype=torch.int32)
+        radii[lo:hi] = 3
+        grads = []
+        for t in leaves.values():
+            g = torch.randn(t.shape, generator=gen)
+            g[radii <= 0] = 0.0
+            grads.append(g)
+        ex.begin_step(radii)
+        _ToyRender.apply(*leaves.values(), *grads).backward()
+        for i, t in enumerate(leaves.values()):      # zero copy: autograd adopted the bucket's slice as .grad
+            assert t.grad.data_ptr() == ex.buckets[step % 2].views[i].data_ptr(), "gradient %d was copied, not adopted" % i
+        before = ex.stats()["sparse_steps"]
+        ex.submit()
+        assert (ex.stats()["sparse_steps"] - before == 1) == expect_sparse[step], step
+        for r, g in zip(ref_leaves, grads):
+            r.grad = g.clone()
+        allreduce_gradients(ref_leaves)               # the dense, blocking sum of the same per-rank gradients
+        kept[step] = [r.grad.clone() for r in ref_leaves]
+        if step >= 1:                                 # the bucket of step - 1 is about to be reused: read it first
+            for v, e in zip(ex.reduced(step - 1), kept[step - 1]):
+                assert torch.equal(v, e), "sparse exchange of step %d differs from the dense sum" % (step - 1)
+    for v, e in zip(ex.reduced(2), kept[2]):
+        assert torch.equal(v, e)
+    ex.drain()
+    st = ex.stats()
+    assert st["zero_copy_tensors"] == 9 and st["copied_tensors"] == 0
+    assert st["sparse_steps"] == 2 and st["bytes_exchanged"] < st["bytes_dense_equivalent"]
+    assert abs(st["union_fraction"] - (160 + 80) / (2 * 200)) < 1e-9
+    # a gradient that did not come through the sink (another producer) is packed, not lost
+    ex.begin_step(None)
+    for t in leaves.values():
+        t.grad = torch.full_like(t, float(rank + 1))
+    ex.submit()
+    for v in ex.reduced(3):
+        assert torch.equal(v, torch.full_like(v, 3.0))
+    assert ex.stats()["copied_tensors"] == 3
 
 
 def test_gradient_allreduce_gloo_world2():

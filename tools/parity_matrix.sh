@@ -14,7 +14,7 @@ python - <<'PY'
 import json
 for l in open("gpurun_out/parity_matrix.jsonl"):
     d = json.loads(l); c = d["config"]; p = d["parity"]
-    print(c["P"], c["K"], c.get("kind", "slam"), "%.0f renders/s" % d["value"], "pass", p["pass"], "outside tie risk", p["pass_outside_tie_risk"],
+    print(c["P"], c["K"], c.get("kind", "slam"), "%.0f renders/s" % d["value"], "pass", p["pass"], "with tie bounds", p["pass_with_tie_bounds"],
           "tie-risk pixels", p["oracle_tie_risk_pixels"], "max grad err/max %.1e" % max(p["grad_err_over_max"].values()),
-          "outside %.1e" % max(p["grad_err_over_max_outside_tie_risk"].values()), "ints", all(p[k] for k in p if k.endswith("_equal")))
+          "beyond bound %.1e" % max(p["grad_err_over_max_beyond_tie_bound"].values()), "ints", all(p[k] for k in p if k.endswith("_equal")))
 PY
