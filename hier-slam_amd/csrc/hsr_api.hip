@@ -572,7 +572,8 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         char* sp = in.scratch;
         take(sp, grow, (size_t)P * gstride);
         StageTimer tm(HSR_STAGE_BWD_ZERO, stream);
-        HSR_HIP_CHECK(hipMemsetAsync(grow, 0, sizeof(float) * (size_t)P * gstride, stream));
+        // only the rows of visible Gaussians (radii > 0): nothing else is added into or read back (hsr_backward_pre.hip)
+        hsr_launch_zero_visible_rows(P, radii, grow, gstride, stream);
         if (!in.colors_precomp && in.shs && in.dL_dsh && in.M > 0)
             HSR_HIP_CHECK(hipMemsetAsync(in.dL_dsh, 0, sizeof(float) * 3 * (size_t)in.M * (size_t)P, stream));
     } else {

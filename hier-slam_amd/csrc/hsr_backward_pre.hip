@@ -107,6 +107,30 @@ __device__ void sh_backward(int idx, int deg, int max_coeffs, float mx, float my
     gmz += (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
 }
 
+// Zero-fill of the packed gradient rows, VISIBLE Gaussians only (radii > 0): the tile kernel adds into no other row and the unpack
+// below reads no other row, so the fill — like the unpack — costs bytes in proportion to what the camera sees, not to the size of
+// the map (the reference zero-fills P x (K + 28) floats per backward whatever is visible, rasterize_points.cu:378-388).  Block =
+// 256 consecutive rows = one contiguous slab of 256 * stride floats, written as float4 (stride is a multiple of 16 floats).
+__global__ void __launch_bounds__(256) zero_visible_rows_kernel(int P, const int* __restrict__ radii, float* __restrict__ grow, int stride)
+{
+    __shared__ uint8_t s_vis[256];
+    const int g0 = blockIdx.x * 256;
+    const int ng = min(256, P - g0);
+    s_vis[threadIdx.x] = (int)threadIdx.x < ng && radii[g0 + threadIdx.x] > 0;
+    __syncthreads();
+    const int q = stride >> 2;                          // float4 per row
+    float4* dst = reinterpret_cast<float4*>(grow + (size_t)g0 * stride);
+    const int total = ng * q;
+    const int drow = 256 / q, dcol = 256 - drow * q;    // e += 256: row += drow, column += dcol (then one carry)
+    int row = (int)threadIdx.x / q, col = (int)threadIdx.x - row * q;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = threadIdx.x; e < total; e += 256) {
+        if (s_vis[row]) dst[e] = z;
+        row += drow; col += dcol;
+        if (col >= q) { col -= q; row++; }
+    }
+}
+
 // KC < 0: legacy mode (sums already accumulated atomically in dL_dmean2D / dL_dconic / dL_ddepth).
 // KC >= 0 (ablate build only): rows mode — this thread first sums the rows of its Gaussian's instances (emission order = ascending
 // tile id inside its rect, a FIXED order: gradients are bit-reproducible), writes the six per-Gaussian sums
@@ -115,6 +139,13 @@ template <int KC>
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    // packed mode: rows of culled Gaussians (radii <= 0) were neither zero-filled nor added into (zero_visible_rows_kernel): they
+    // are not read either — their gradients are the zeros written below
+    __shared__ uint8_t s_vis[256];
+    if (KC < 0 && a.grow) {
+        s_vis[threadIdx.x] = idx < a.P && a.radii[idx] > 0;
+        __syncthreads();
+    }
     if (KC < 0 && a.grow && a.K > 0 && a.out_semantics) {
         // packed mode: the block unpacks the semantic columns of its 256 rows cooperatively — consecutive
         // lanes read consecutive floats of a row and write one contiguous [256, K] slab of dL_dsemantics
@@ -131,7 +162,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
             float v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                v[u] = src[(size_t)gi * a.grow_stride + c];
+                v[u] = s_vis[gi] ? src[(size_t)gi * a.grow_stride + c] : 0.f;
                 gi += dgi; c += dc;
                 if (c >= K) { c -= K; gi++; }
             }
@@ -139,7 +170,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
             for (int u = 0; u < 4; u++) dst[e + 256 * u] = v[u];
         }
         for (; e < total; e += 256) {
-            dst[e] = src[(size_t)gi * a.grow_stride + c];
+            dst[e] = s_vis[gi] ? src[(size_t)gi * a.grow_stride + c] : 0.f;
             gi += dgi; c += dc;
             if (c >= K) { c -= K; gi++; }
         }
@@ -175,9 +206,11 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
     } else if (a.grow) {
         // packed mode: unpack this Gaussian's atomically accumulated row into the reference's arrays
         const float4* r = reinterpret_cast<const float4*>(a.grow + (size_t)idx * a.grow_stride);
-        const float4 r0 = r[0], r1 = r[1];
+        const bool vis = s_vis[threadIdx.x];
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r0 = vis ? r[0] : zero4, r1 = vis ? r[1] : zero4;
         float d_r = 0.f, d_g = 0.f, d_b = 0.f, d_dep = 0.f, d_op = 0.f;
-        if (!a.geo) {
+        if (!a.geo && vis) {
             const float* dr = a.grow + (size_t)idx * a.grow_stride + hsr_grow_direct0(a.K);  // r, g, b, depth, opacity (direct)
             d_r = dr[0]; d_g = dr[1]; d_b = dr[2]; d_dep = dr[3]; d_op = dr[4];
         }
@@ -337,6 +370,13 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
 }
 
 }  // namespace
+
+int hsr_launch_zero_visible_rows(int P, const int* radii, float* grow, int stride, hipStream_t stream)
+{
+    if (P <= 0) return HSR_OK;
+    zero_visible_rows_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, radii, grow, stride);
+    return HSR_OK;
+}
 
 int hsr_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t stream)
 {

@@ -260,6 +260,7 @@ struct PreBwdArgs {
     int geo;                 // geometry-only rows (16 floats: columns 0..6, depth complete in column 6); out_color / out_opacity / out_semantics NULL
 };
 int hsr_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t stream);
+int hsr_launch_zero_visible_rows(int P, const int* radii, float* grow, int stride, hipStream_t stream);   // packed rows of visible Gaussians := 0
 
 #ifndef HSR_OK
 #define HSR_OK 0

@@ -348,3 +348,104 @@ def test_debug_mode_checks_every_launch_and_dumps_snapshots(tmp_path, monkeypatc
     with pytest.raises(RuntimeError):
         outs[0].sum().backward()
     assert not os.path.exists("snapshot_bw.dump")
+
+
+def _fwd_bwd(cam, sc, up, dev):
+    leaf, outs = _render_sem(cam, sc, dev)
+    color, radii, sem, depth, median, opac = outs
+    upd = {n: v.to(dev) for n, v in up.items()}
+    loss = (color * upd["color"]).sum() + (sem * upd["semantic"]).sum() + (depth * upd["depth"]).sum() \
+        + (median * upd["median"]).sum() + (opac * upd["opacity"]).sum()
+    loss.backward()
+    return [o.detach() for o in (color, sem, depth, median, opac)], radii, {n: t.grad for n, t in leaf.items()}
+
+
+def test_two_renders_on_two_non_default_streams_match_the_default_stream():
+    """The C ABI takes the launch stream explicitly and the glue passes torch's CURRENT stream; the forward's speculative tail and
+    the host-mapped num_rendered slot (one per thread and device, hsr_api.hip) must not assume the default stream.  Two scenes are
+    rendered forward-forward-backward-backward on two side streams, interleaved, and compared with their default-stream runs:
+    images and radii bit for bit (the forward has no atomics), gradients to atomics-order noise."""
+    dev = torch.device("cuda:0")
+    scenes_ = [scenes.build(203, 131, 3000, 26, seed=5, kind="slam"), scenes.build(160, 96, 2500, 16, seed=6, kind="aniso", scale_mult=2.0)]
+    ref = [_fwd_bwd(cam, sc, up, dev) for cam, sc, up in scenes_]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    pend = []
+    for (cam, sc, up), st in zip(scenes_, streams):
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            leaf, outs = _render_sem(cam, sc, dev)
+            pend.append((leaf, outs, {n: v.to(dev) for n, v in up.items()}))
+    got = []
+    for (leaf, outs, upd), st in zip(pend, streams):
+        with torch.cuda.stream(st):
+            color, radii, sem, depth, median, opac = outs
+            ((color * upd["color"]).sum() + (sem * upd["semantic"]).sum() + (depth * upd["depth"]).sum()
+             + (median * upd["median"]).sum() + (opac * upd["opacity"]).sum()).backward()
+            got.append(([o.detach() for o in (color, sem, depth, median, opac)], radii, {n: t.grad for n, t in leaf.items()}))
+    for st in streams:
+        st.synchronize()
+    for (imgs_r, radii_r, gr_r), (imgs_g, radii_g, gr_g) in zip(ref, got):
+        assert torch.equal(radii_r, radii_g)
+        for a, b in zip(imgs_r, imgs_g):
+            assert torch.equal(a, b)
+        for n in gr_r:
+            a, b = gr_r[n], gr_g[n]
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), n
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second GPU")
+def test_second_device_matches_the_first():
+    """the same render on cuda:1 (device guard, per-device read-back slot, per-device binning hint)"""
+    cam, sc, up = scenes.build(203, 131, 3000, 26, seed=5, kind="slam")
+    a = _fwd_bwd(cam, sc, up, torch.device("cuda:0"))
+    b = _fwd_bwd(cam, sc, up, torch.device("cuda:1"))
+    assert torch.equal(a[1].cpu(), b[1].cpu())
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x.cpu(), y.cpu())
+    for n in a[2]:
+        assert float((a[2][n].cpu() - b[2][n].cpu()).abs().max()) <= 1e-5 * max(1.0, float(a[2][n].abs().max())), n
+
+
+@pytest.mark.parametrize("glue", ["compiled", "ctypes"])
+def test_gradient_exchange_bucket_is_written_by_the_backward_itself(glue):
+    """hsr_utils.parallel.GradientExchange on one rank: after backward() every leaf's .grad IS a slice of the exchange bucket (the
+    backward wrote it there through the gradient sink, autograd adopted it) and holds the same values as an ordinary run."""
+    import subprocess
+    import sys
+    code = r'''
+import sys; sys.path[:0]=['hier-slam_amd','tests']
+import torch, scenes
+from diff_gaussian_rasterization import GaussianRasterizer_semantic
+from hsr_utils.parallel import GradientExchange
+from harness import _cam_to
+cam, sc, up = scenes.build(160, 96, 2500, 26, seed=3, kind="aniso", scale_mult=2.0)
+dev = torch.device("cuda:0"); camd = _cam_to(cam, dev)
+names = ("means3D", "colors_precomp", "semantics_precomp", "opacities", "scales", "rotations")
+def run(ex):
+    leaf = {n: sc[n].to(dev).clone().requires_grad_(True) for n in names}
+    if ex == "x":
+        ex = GradientExchange({"raster." + n: leaf[n] for n in names}, dev, depth=2)
+    outs = GaussianRasterizer_semantic(camd)(means2D=torch.zeros(2500, 3, device=dev, requires_grad=True), **leaf)
+    if ex is not None:
+        ex.begin_step(outs[1])
+    torch.autograd.backward([outs[0], outs[2], outs[3], outs[4], outs[5]],
+                            [up[n].to(dev) for n in ("color", "semantic", "depth", "median", "opacity")])
+    if ex is not None:
+        for i, n in enumerate(names):
+            assert leaf[n].grad.data_ptr() == ex.buckets[0].views[i].data_ptr(), n
+        ex.submit(); ex.drain()
+        st = ex.stats(); assert st["zero_copy_tensors"] == 6 and st["copied_tensors"] == 0, st
+    torch.cuda.synchronize()
+    return {n: leaf[n].grad.clone() for n in names}
+a, b = run(None), run("x")
+for n in names:
+    assert float((a[n] - b[n]).abs().max()) <= 1e-5 * max(1.0, float(a[n].abs().max())), n
+print("ok")
+'''
+    env = dict(os.environ)
+    if glue == "ctypes":
+        env["HSR_GLUE"] = "ctypes"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

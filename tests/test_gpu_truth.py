@@ -6,7 +6,9 @@ there are three explanations — a defect in a kernel, a threshold decision take
 bounds), or two correct fp32 evaluations of an ill-conditioned expression landing apart — and only a third, more exact
 evaluation can tell the last from the first: if HIP and the oracle are EQUIDISTANT from the truth, neither is wrong; if the
 oracle sits on the truth and HIP does not, HIP is.  The named cases are the three the 1 000-case fuzz run of round 2 left
-unexplained (HSR_FUZZ_CASES=1000 HSR_FUZZ_SEED=5: one `grad means3D` element each at 1.6e-4 element-wise vs the fp32 oracle)."""
+unexplained (HSR_FUZZ_CASES=1000 HSR_FUZZ_SEED=9: one `grad means3D` element each at 1.6e-4 element-wise vs the fp32 oracle) and the
+two that round 3's first run of the same generator with seed 5 produced (a `grad means3D` element at 1.05e-4, a `grad rotations`
+element at 1.26e-4).  Which cases land outside the bound changes from run to run (fp32 atomics order); the class does not."""
 import json
 import os
 import zlib
@@ -20,11 +22,12 @@ from test_gpu_fuzz import _cases
 
 pytestmark = pytest.mark.gpu
 
-ROUND2_OUTLIERS = ("537_88x79_P2500_K53_aniso_x3", "565_170x112_P2500_K74_aniso_x3", "798_69x39_P300_K1_aniso_x1")
+FUZZ_OUTLIERS = [(9, "537_88x79_P2500_K53_aniso_x3"), (9, "565_170x112_P2500_K74_aniso_x3"), (9, "798_69x39_P300_K1_aniso_x1"),
+                 (5, "106_175x18_P2500_K53_aniso_x3"), (5, "677_168x126_P2500_K3_aniso_x1")]
 REPORTS = {}
 
 
-def _scene(name, n=1000, seed=5):
+def _scene(name, seed, n=1000):
     cfg = dict(_cases(n, seed))[name]
     W, H, P, K, kind, sm, semantic, variant, bg, behind = cfg
     cam, sc, up = scenes.build(W, H, P, K, seed=zlib.crc32(name.encode()) % 1000, kind=kind, scale_mult=sm, bg=bg, behind_frac=behind)
@@ -43,9 +46,9 @@ def _check(name, rep):
         assert h["elementwise"] <= max(1e-4, 3.0 * o["elementwise"] + 2e-5), (name, tname, h, o)
 
 
-@pytest.mark.parametrize("name", ROUND2_OUTLIERS)
-def test_round2_fuzz_outliers_against_the_truth(name):
-    cam, sc, up, semantic, variant = _scene(name)
+@pytest.mark.parametrize("seed,name", FUZZ_OUTLIERS, ids=[n for _, n in FUZZ_OUTLIERS])
+def test_fuzz_outliers_against_the_truth(seed, name):
+    cam, sc, up, semantic, variant = _scene(name, seed)
     _check(name, truth_report(cam, sc, up, semantic=semantic, variant=variant))
 
 
