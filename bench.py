@@ -257,14 +257,15 @@ class Workload:
 
     names = ("means3D", "colors_precomp", "semantics_precomp", "opacities", "scales", "rotations")
 
-    def __init__(self, dev, W, H, P, K, kind, rank=0, world=1, device_tensors=True):
+    def __init__(self, dev, W, H, P, K, kind, rank=0, world=1, device_tensors=True, behind_frac=0.0):
         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer_semantic
         from hsr_utils.camera import replica_intrinsics, setup_camera_tensors
         from hsr_utils.synthetic import make_scene, make_upstream_grads
         self.dev, self.W, self.H, self.P, self.K, self.kind, self.world = dev, W, H, P, K, kind, world
         kmat = replica_intrinsics(W, H)
         self.cam_cpu = setup_camera_tensors(W, H, kmat, perturbed_w2c(rank))
-        self.sc = make_scene(P, W, H, K, kmat, seed=0, kind=kind)  # same Gaussians on every rank (replicated parameters)
+        self.sc = make_scene(P, W, H, K, kmat, seed=0, kind=kind, behind_frac=behind_frac)  # same Gaussians on every rank (replicated parameters)
+        self.behind_frac = behind_frac
         self.up = make_upstream_grads(W, H, K, seed=1 + rank)
         self.exchange = None
         self.info = {}
@@ -275,8 +276,9 @@ class Workload:
             self.renderer = GaussianRasterizer_semantic(cam)
 
     def describe(self):
-        return ("semantic fwd+bwd render, %dx%d, P=%d %s Gaussians, K=%d semantic channels, dense upstream grads on "
-                "colour/semantic/depth/median/opacity" % (self.W, self.H, self.P, self.kind, self.K))
+        return ("semantic fwd+bwd render, %dx%d, P=%d %s Gaussians%s, K=%d semantic channels, dense upstream grads on "
+                "colour/semantic/depth/median/opacity" % (self.W, self.H, self.P, self.kind,
+                                                          (" (%.0f %% behind the camera)" % (100 * self.behind_frac)) if self.behind_frac else "", self.K))
 
     def release(self):
         self.leaf = self.upd = self.renderer = None
@@ -393,6 +395,7 @@ def main():
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=680)
     ap.add_argument("--kind", default="slam", choices=["slam", "aniso"])
+    ap.add_argument("--behind-frac", type=float, default=0.0, help="fraction of the Gaussians placed behind the camera (culled): a camera that sees part of the map")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (also skips the parity block)")
     ap.add_argument("--no-parity", action="store_true", help="time the oracle but do not compare the GPU step with it")
@@ -451,7 +454,7 @@ def main():
     from hsr_utils.parallel import GradientExchange
 
     W, H, K, P = args.width, args.height, args.K, args.P
-    wl = Workload(dev, W, H, P, K, args.kind, rank, world)
+    wl = Workload(dev, W, H, P, K, args.kind, rank, world, behind_frac=args.behind_frac)
     exch = None
     if world > 1:
         # N > 1: the one exchange step of the sharded path.  The leaves' .grad tensors are VIEWS of the exchange
@@ -534,7 +537,7 @@ def main():
                 _, first = cpu_baseline(a2, swl.sc, swl.cam_cpu, swl.up)
                 e["parity"] = parity_block(swl.cam_cpu, swl.sc, swl.up, first, dev, brief=True)
             wl.release()
-            wl = Workload(dev, W, H, P, K, args.kind, 0, 1, device_tensors=False)
+            wl = Workload(dev, W, H, P, K, args.kind, 0, 1, device_tensors=False, behind_frac=args.behind_frac)
             out["cpu_baseline"], oracle_first = cpu_baseline(args, wl.sc, wl.cam_cpu, wl.up)
             if args.no_parity:
                 oracle_first[2].free()

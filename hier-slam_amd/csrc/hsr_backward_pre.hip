@@ -162,7 +162,11 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
             float v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                v[u] = s_vis[gi] ? src[(size_t)gi * a.grow_stride + c] : 0.f;
+                // unconditional load (a culled Gaussian's lanes re-read the slab's first word, value discarded): a load under a
+                // divergent condition would be waited for where it is issued instead of four being in flight
+                const bool vs = s_vis[gi];
+                const float x = src[vs ? (size_t)gi * a.grow_stride + c : (size_t)0];
+                v[u] = vs ? x : 0.f;
                 gi += dgi; c += dc;
                 if (c >= K) { c -= K; gi++; }
             }
@@ -170,7 +174,9 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
             for (int u = 0; u < 4; u++) dst[e + 256 * u] = v[u];
         }
         for (; e < total; e += 256) {
-            dst[e] = s_vis[gi] ? src[(size_t)gi * a.grow_stride + c] : 0.f;
+            const bool vs = s_vis[gi];
+            const float x = src[vs ? (size_t)gi * a.grow_stride + c : (size_t)0];
+            dst[e] = vs ? x : 0.f;
             gi += dgi; c += dc;
             if (c >= K) { c -= K; gi++; }
         }
@@ -205,14 +211,18 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
             if (c < a.K) a.out_semantics[(size_t)idx * a.K + c] = racc[8 + c];
     } else if (a.grow) {
         // packed mode: unpack this Gaussian's atomically accumulated row into the reference's arrays
-        const float4* r = reinterpret_cast<const float4*>(a.grow + (size_t)idx * a.grow_stride);
+        // a culled Gaussian's lane re-reads the first row of the block's slab (unconditional loads, values discarded)
         const bool vis = s_vis[threadIdx.x];
+        const size_t row = vis ? (size_t)idx : (size_t)blockIdx.x * 256;
+        const float4* r = reinterpret_cast<const float4*>(a.grow + row * a.grow_stride);
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 r0 = vis ? r[0] : zero4, r1 = vis ? r[1] : zero4;
+        const float4 l0 = r[0], l1 = r[1];
+        const float4 r0 = vis ? l0 : zero4, r1 = vis ? l1 : zero4;
         float d_r = 0.f, d_g = 0.f, d_b = 0.f, d_dep = 0.f, d_op = 0.f;
-        if (!a.geo && vis) {
-            const float* dr = a.grow + (size_t)idx * a.grow_stride + hsr_grow_direct0(a.K);  // r, g, b, depth, opacity (direct)
-            d_r = dr[0]; d_g = dr[1]; d_b = dr[2]; d_dep = dr[3]; d_op = dr[4];
+        if (!a.geo) {
+            const float* dr = a.grow + row * a.grow_stride + hsr_grow_direct0(a.K);  // r, g, b, depth, opacity (direct)
+            const float x0 = dr[0], x1 = dr[1], x2 = dr[2], x3 = dr[3], x4 = dr[4];
+            if (vis) { d_r = x0; d_g = x1; d_b = x2; d_dep = x3; d_op = x4; }
         }
         g_m2x = r0.x; g_m2y = r0.y; g_cx = r0.z; g_cy = r0.w; g_cw = r1.x;
         g_depth = r1.z + d_dep;

@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
     uint32_t last_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0, Dd = 0, Mm = 0;
     uint32_t median_at = 0;   // 1 + list position of the splat at which T crossed 0.5 (ImgState::median_pos)
+    float median_D = 15.0f;   // its depth (forward.cu:511-515; default 15.0, :450)
     float S[KC > 0 ? KC : 1];
 #pragma unroll
     for (int c = 0; c < (KC > 0 ? KC : 1); c++) S[c] = 0.f;
@@ -254,6 +255,18 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
         id_next = fetch_id(BATCH);
         load_record(id0);
     }
+    // Median depth = depth of the splat at which T crossed 0.5.  The blend loop only records WHERE (median_at: one select per visit
+    // instead of two); the depth is read once, right after the batch in which the crossing happened, from that batch's staged row
+    // (channel KC + 1) while it is still in LDS — round 2 fetched it in the epilogue from global memory (point_list, then the splat's
+    // record: two dependent gathers per pixel at the end of every tile, and 19 MB of extra FETCH_SIZE per launch at the headline).
+    auto resolve_median = [&](int start) {
+        if (BASE && median_at > (uint32_t)start) {   // set during this batch (T crosses 0.5 once)
+            const int j = (int)median_at - 1 - start;
+            constexpr int c = KC + 1;
+            constexpr int pos = (QS && c / 16 < NGF) ? (16 * (c / 16) + 4 * (c % 4) + (c % 16) / 4) : c;
+            median_D = reinterpret_cast<const float*>(s_row)[j * RW + pos];
+        }
+    };
 
 
     for (int start = 0; start < n; start += BATCH) {
@@ -436,6 +449,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
 #endif
                 }
                 TRF_ADD(tr_blend, tl0);
+                resolve_median(start);
                 continue;
             }
             int j_next = (int)list[0];
@@ -489,6 +503,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
 #endif
             }
             TRF_ADD(tr_blend, tl0);
+            resolve_median(start);
             continue;
         }
 
@@ -542,6 +557,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
                 }
             }
         }
+        resolve_median(start);
     }
 
     if (PF && pf_sink == 1.2345678e-30f) T = pf_sink;   // never true for data that matters; keeps the touch loads alive
@@ -558,11 +574,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
             a.out_color[N + pix_id] = C1;
             a.out_color[2 * N + pix_id] = C2;
             a.out_depth[pix_id] = Dd;
-            // median depth = depth of the splat at which T crossed 0.5 (forward.cu:511-515, default 15.0 :450): the loop only records
-            // WHERE (one select per visit instead of two), the value is the staged record's depth, fetched once here
-            float median_D = 15.0f;
-            if (median_at != 0u) median_D = a.rec[4 * (size_t)a.point_list[range.x + median_at - 1u]].z;
-            a.out_median_depth[pix_id] = median_D;
+            a.out_median_depth[pix_id] = median_D;   // resolve_median()
             a.out_opacity[pix_id] = 1.0f - T;
             if (MASK) a.out_mask[pix_id] = Mm;
         }

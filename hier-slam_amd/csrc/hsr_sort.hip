@@ -451,6 +451,136 @@ __global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, const uint2*
     }
 }
 
+// ---- per-tile sort, TWO waves per tile (round 3) ----
+// At the headline workload every one of the 3 225 tiles holds 263..448 entries: tile_sort_wave_kernel gives each to ONE wave with 8
+// elements per lane, and the launch — 3.15 waves per SIMD, all resident, every wave running the same 45-step network at a third of the
+// SIMD's issue rate with a dependent LDS round trip in 21 of the steps — lasts as long as one wave does (27.8 us; waves average 19 us of
+// life, profiles/r02_h_final.json).  Two waves per tile halve the elements per lane (E = 4 for 257..512 entries: 128 lanes x 4), so every
+// step is half as long and twice as many waves hide each other's LDS round trips.  Thread = tid128 of the pair, element e = E * tid128 + r;
+// a step with stride j >= E exchanges with thread tid128 ^ (j / E): inside the wave for j / E < 64 (wave-level fence), and across the two
+// waves for exactly ONE step of the whole network (k = N, j = N / 2), bracketed by two workgroup barriers (partner's stores visible;
+// partner's loads done before the next step overwrites the slots).  Two pairs = two tiles per 256-thread workgroup; every pair
+// passes exactly those two barriers whatever its tile holds.  16 KB of exchange buffers: all 1 613 workgroups of the headline resident.  Tiles above TP_MAX entries are left to the whole workgroup afterwards (block_sort_tile), as in
+// tile_sort_wave_kernel.
+constexpr int TP_MAX = 1024;   // E = 8
+
+template <int E>
+__device__ __forceinline__ void pair_bitonic(uint64_t (&x)[E], int tid, ulonglong2* buf)
+{
+    constexpr int N = 128 * E;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    if ((r & j) == 0) {
+                        const bool up = k < E ? ((r & k) == 0) : (((E * tid) & k) == 0);
+                        const uint64_t a = x[r], b = x[r + j];
+                        const bool sw = (a > b) == up;
+                        x[r] = sw ? b : a;
+                        x[r + j] = sw ? a : b;
+                    }
+                }
+            } else {
+                const int m = j / E;                   // partner thread = tid ^ m
+                const bool cross = m >= 64;            // the one step that pairs the two waves
+#pragma unroll
+                for (int q = 0; q < E / 2; q++) buf[q * 128 + tid] = make_ulonglong2(x[2 * q], x[2 * q + 1]);
+                if (cross) {
+                    __syncthreads();
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                const bool keep_min = ((tid & m) == 0) == (((E * tid) & k) == 0);
+#pragma unroll
+                for (int q = 0; q < E / 2; q++) {
+                    const ulonglong2 y = buf[q * 128 + (tid ^ m)];
+                    const uint64_t a0 = x[2 * q], a1 = x[2 * q + 1];
+                    x[2 * q] = keep_min ? (a0 < y.x ? a0 : y.x) : (a0 > y.x ? a0 : y.x);
+                    x[2 * q + 1] = keep_min ? (a1 < y.y ? a1 : y.y) : (a1 > y.y ? a1 : y.y);
+                }
+                // the next exchange's stores stay behind these loads
+                if (cross) {
+                    __syncthreads();
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void pair_sort_tile(int r0, int n, int tid, uint64_t tile_hi, uint64_t* __restrict__ keys,
+                                               uint32_t* __restrict__ vals, ulonglong2* buf)
+{
+    uint64_t x[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int e = E * tid + r;
+        x[r] = e < n ? keys[r0 + e] : ~0ull;
+    }
+    pair_bitonic<E>(x, tid, buf);
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int e = E * tid + r;
+        if (e < n) {
+            keys[r0 + e] = tile_hi | (x[r] >> 32);
+            vals[r0 + e] = (uint32_t)x[r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_sort_pair_kernel(int T, const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
+                                                             uint32_t* __restrict__ vals_alt, int gid_passes, int big_too, BinDevRef ref)
+{
+    // pair phase: per pair E/2 <= 4 rows of 128 x 16 bytes; workgroup phase: comp[TS_MAX], hist[256], wcnt[4][256]
+    constexpr int RAW_WG = TS_MAX * 8 + 256 * 4 + 4 * 256 * 4, RAW_PAIR = 2 * 4 * 128 * 16;
+    constexpr int RAW = RAW_WG > RAW_PAIR ? RAW_WG : RAW_PAIR;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[RAW];
+    __shared__ int s_big[2];
+    if (ref.base) {   // speculative forward: the arrays live where num_rendered says
+        BinState bs;
+        if (!hsr_bin_resolve(ref, *ref.R_dev, &bs)) return;
+        keys = bs.keys; vals = bs.vals; keys_alt = bs.keys_unsorted; vals_alt = bs.vals_unsorted;
+    }
+    const int pair = threadIdx.x >> 7, tid = threadIdx.x & 127;
+    const int tile = blockIdx.x * 2 + pair;
+    int n = 0, r0 = 0;
+    if (tile < T) {
+        const uint2 rg = ranges[tile];
+        r0 = (int)rg.x;
+        n = (int)(rg.y - rg.x);
+    }
+    if (tid == 0) s_big[pair] = n > TP_MAX;
+    {
+        ulonglong2* buf = reinterpret_cast<ulonglong2*>(s_raw) + pair * (4 * 128);
+        const uint64_t tile_hi = (uint64_t)tile << 32;
+        // every pair passes exactly two workgroup barriers here (inside the network, or the bare ones of a pair with nothing to sort)
+        if (n > 0 && n <= 256) pair_sort_tile<2>(r0, n, tid, tile_hi, keys, vals, buf);
+        else if (n > 256 && n <= 512) pair_sort_tile<4>(r0, n, tid, tile_hi, keys, vals, buf);
+        else if (n > 512 && n <= TP_MAX) pair_sort_tile<8>(r0, n, tid, tile_hi, keys, vals, buf);
+        else { __syncthreads(); __syncthreads(); }
+    }
+    if (!big_too) return;   // the larger tiles have a launch of their own (one workgroup per tile)
+    __syncthreads();
+    uint64_t* comp = reinterpret_cast<uint64_t*>(s_raw);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(s_raw + TS_MAX * 8);
+    uint32_t (*wcnt)[256] = reinterpret_cast<uint32_t (*)[256]>(s_raw + TS_MAX * 8 + 256 * 4);
+    for (int w = 0; w < 2; w++) {
+        if (!s_big[w]) continue;
+        block_sort_tile(blockIdx.x * 2 + w, ranges, keys, vals, keys_alt, vals_alt, gid_passes, 1, comp, hist, wcnt);
+        __syncthreads();
+    }
+}
+
 // Sorts the R pairs on key bits [0, end_bit) — the contract of the reference's cub::DeviceRadixSort::SortPairs
 // call (rasterizer_impl.cu:307-312) — in two phases: stable LSD passes over the TILE bits only (bits 32..end_bit,
 // at most 8 per pass), then one per-tile sort by depth (tile_sort_kernel).  ranges[] is produced between the two
@@ -508,6 +638,12 @@ int hsr_launch_tile_sort(BinState& b, int T, int P, const uint2* ranges, hipStre
     // (four tiles per workgroup, one after the other) while they are the exception, in a launch of their own (one workgroup
     // per tile) when the previous frame averaged more than 800 entries per tile
     const bool many_big = avg_per_tile_hint > 800;
+    // round 3: two waves per tile (tile_sort_pair_kernel); HSR_SORT_IMPL=wave keeps one wave per tile (parity-tested selector)
+    static const bool one_wave = getenv("HSR_SORT_IMPL") && !strcmp(getenv("HSR_SORT_IMPL"), "wave");
+    if (!one_wave)
+        tile_sort_pair_kernel<<<(T + 1) / 2, 256, 0, stream>>>(T, ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8,
+                                                               many_big ? 0 : 1, r);
+    else
     tile_sort_wave_kernel<<<(T + 3) / 4, 256, 0, stream>>>(T, ranges, b.keys, b.vals, b.keys_unsorted, b.vals_unsorted, (bits + 7) / 8,
                                                            many_big ? 0 : 1, r);
     if (many_big)

@@ -230,6 +230,14 @@ typedef struct HsroState {
 
 static int g_median_rule = 0;
 static long g_median_disagree = 0;
+/* Accumulation model of the backward's per-Gaussian sums.  0 (default, THE ORACLE): double, rounded once — order-independent.
+ * 1: fp32, the tiles visited in a seeded random order, one thread: ONE of the orders in which the reference's fp32 atomicAdds
+ * (backward.cu:616-663, :828-896) — or the HIP kernels' — can arrive.  Different seeds give different, equally valid fp32 results;
+ * their spread is the noise floor no fp32-atomic implementation can go below (tests/harness.truth_report uses it to tell an
+ * ill-conditioned gradient from a defect). */
+static int g_accum_fp32 = 0;
+static unsigned g_accum_seed = 0;
+void hsro_set_accumulation(int fp32, unsigned seed) { g_accum_fp32 = fp32 ? 1 : 0; g_accum_seed = seed; }
 void hsro_set_median_rule(int rule) { g_median_rule = rule ? 1 : 0; }
 long hsro_last_median_rule_disagreements(void) { return g_median_disagree; }
 
@@ -706,7 +714,7 @@ typedef struct {
 } HsroBwdCtx;
 
 static int pixel_backward(const HsroBwdCtx* c, size_t pix_id, float pfx, float pfy, uint32_t r0, uint32_t r1, real T_final,
-                          int last_contributor, uint32_t median_at, HsroDecision ovr, real* dsem, double* acc, double* local)
+                          int last_contributor, uint32_t median_at, HsroDecision ovr, real* dsem, double* acc, double* local, float* acc32)
 {
     const HsroState* s = c->s;
     const size_t N = c->N; const int K = c->K, NA = c->NA;
@@ -718,7 +726,7 @@ static int pixel_backward(const HsroBwdCtx* c, size_t pix_id, float pfx, float p
     for (int ch = 0; ch < K; ch++) dsem[ch] = c->dL_dpix_sem[(size_t)ch * N + pix_id];
     real accum_depth_rec = 0, accum_op_rec = 0, last_alpha = 0, last_depth = 0, last_op = 0;
     int pixel_disagrees = 0;
-#define ADD(col, v) do { if (local) a[col] += (double)(v); else { _Pragma("omp atomic") a[col] += (double)(v); } } while (0)
+#define ADD(col, v) do { if (local) a[col] += (double)(v); else if (acc32) a32[col] += (float)(v); else { _Pragma("omp atomic") a[col] += (double)(v); } } while (0)
     for (uint32_t ii = r1; ii > r0; ii--) { /* back to front, backward.cu:562, :771 */
         contributor--;
         if ((int64_t)contributor >= (int64_t)last_contributor) continue;
@@ -737,6 +745,7 @@ static int pixel_backward(const HsroBwdCtx* c, size_t pix_id, float pfx, float p
         real test_T = T / (1.f - alpha);
         const real w = alpha * test_T;
         double* a = local ? local + (size_t)(ii - 1 - r0) * NA : acc + (size_t)id * NA;
+        float* a32 = acc32 ? acc32 + (size_t)id * NA : 0;
         real dL_dalpha = 0.0f;
         for (int ch = 0; ch < NUM_CHANNELS; ch++) {
             const real cval = c->colors[(size_t)id * NUM_CHANNELS + ch];
@@ -869,9 +878,23 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
     long median_disagree = 0;
     const HsroDecision no_ovr = {0, 0};
 
+    /* fp32 accumulation model (hsro_set_accumulation): float sums, tiles in a seeded random order, one thread */
+    const int fp32_acc = g_accum_fp32;
+    float* acc32 = fp32_acc ? (float*)calloc(Pa * (size_t)NA, sizeof(float)) : 0;
+    long* order = (long*)malloc(sizeof(long) * (Tn ? Tn : 1));
+    for (size_t i = 0; i < Tn; i++) order[i] = (long)i;
+    if (fp32_acc) {
+        uint64_t st = 0x9E3779B97F4A7C15ull ^ ((uint64_t)g_accum_seed * 0xD1B54A32D192ED03ull + 1ull);
+        for (size_t i = Tn; i > 1; i--) {
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            const size_t j = (size_t)(st % i);
+            const long t_ = order[i - 1]; order[i - 1] = order[j]; order[j] = t_;
+        }
+    }
     /* ---- renderCUDA (backward.cu:472-666) / renderCUDA_SEM (backward.cu:669-899) ---- */
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : median_disagree)
-    for (long tile = 0; tile < (long)Tn; tile++) {
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : median_disagree) if (!fp32_acc)
+    for (long ti = 0; ti < (long)Tn; ti++) {
+        const long tile = order[ti];
         const uint32_t ty = (uint32_t)(tile / gx), tx = (uint32_t)(tile % gx);
         const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
         real* dsem = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
@@ -881,11 +904,13 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
                 if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
                 size_t pix_id = (size_t)W * py + px;
                 median_disagree += pixel_backward(&bc, pix_id, (float)px, (float)py, r0, r1, s->final_T[pix_id], (int)s->n_contrib[pix_id],
-                                                  s->median_pos[pix_id], no_ovr, dsem, acc, 0);
+                                                  s->median_pos[pix_id], no_ovr, dsem, acc, 0, acc32);
             }
         free(dsem);
     }
+    free(order);
     g_median_disagree = median_disagree;
+    if (acc32) { for (size_t i = 0; i < Pa * (size_t)NA; i++) acc[i] = (double)acc32[i]; free(acc32); }
     for (int i = 0; i < P; i++) {
         const double* a = acc + (size_t)i * NA;
         dL_dmean2D[3 * i] = (real)a[0]; dL_dmean2D[3 * i + 1] = (real)a[1]; dL_dmean2D[3 * i + 2] = 0.f;
@@ -935,7 +960,7 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
             double* alt = (double*)malloc((nl ? nl : 1) * (size_t)NA * sizeof(double));
             HsroPixFwd f;
             pixel_forward(s, feat, semantics, K, r0, r1, (float)px, (float)py, no_ovr, 1, Sacc, &f);
-            pixel_backward(&bc, (size_t)pix, (float)px, (float)py, r0, r1, f.T, (int)f.last_contributor, f.median_at, no_ovr, dsem, 0, base);
+            pixel_backward(&bc, (size_t)pix, (float)px, (float)py, r0, r1, f.T, (int)f.last_contributor, f.median_at, no_ovr, dsem, 0, base, 0);
             n_pix++; n_dec += f.ndec; n_ovf += f.overflow;
             for (int d = 0; d < f.ndec; d++) {
                 if (f.dec[d].kind == 4) {
@@ -949,7 +974,7 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
                 HsroPixFwd g;
                 pixel_forward(s, feat, semantics, K, r0, r1, (float)px, (float)py, f.dec[d], 0, Sacc, &g);
                 memset(alt, 0, (nl ? nl : 1) * (size_t)NA * sizeof(double));
-                pixel_backward(&bc, (size_t)pix, (float)px, (float)py, r0, r1, g.T, (int)g.last_contributor, g.median_at, f.dec[d], dsem, 0, alt);
+                pixel_backward(&bc, (size_t)pix, (float)px, (float)py, r0, r1, g.T, (int)g.last_contributor, g.median_at, f.dec[d], dsem, 0, alt, 0);
                 for (size_t j = 0; j < nl; j++) {
                     double* da = alt + j * NA; const double* ba = base + j * NA;
                     int any = 0;

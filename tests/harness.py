@@ -300,12 +300,16 @@ def parity_report(out_g, gr_g, st_g, out_o, gr_o, st_o, semantic=True):
     return rep
 
 
-def truth_report(cam, sc, up, semantic=True, variant="sr", extra=None, threads=0):
+def truth_report(cam, sc, up, semantic=True, variant="sr", extra=None, threads=0, atomics_seeds=()):
     """HIP, the fp32 oracle and the truth build (oracle arithmetic in double on the same fp32 lists) on one scene: per tensor, how far
     HIP and the fp32 oracle each sit from the truth and from each other — tensor-wide (err / max|truth|) and element-wise
     (err_i / max(|truth_i|, floor * max|truth|), the quantity the 1e-4 bar is applied to) — after the oracle's tie bound has been
     allowed on the entries it covers.  If HIP and the oracle are two fp32 evaluations of an ill-conditioned expression, both
-    distances are of the same size; a defect shows as HIP being the farther one by a wide margin."""
+    distances are of the same size; a defect shows as HIP being the farther one by a wide margin.
+    atomics_seeds: for each seed the oracle's backward is run once more with its per-Gaussian sums accumulated in fp32 in a seeded
+    random tile order — a model of the reference's own fp32 atomicAdd accumulation (backward.cu:616-663, :828-896), whose arrival order
+    is arbitrary — and the largest distance of those runs from the truth is reported as `fp32_atomics_model_vs_truth`: the noise floor
+    of ANY implementation that sums in fp32 (the oracle proper sums in double)."""
     out_g, gr_g, st_g = run_gpu(cam, sc, up, semantic=semantic, variant=variant, extra=extra)
     out_o, gr_o, st_o = run_oracle(cam, sc, up, semantic=semantic, variant=variant, extra=extra, threads=threads)
     out_t, gr_t, st_t = run_oracle(cam, sc, up, semantic=semantic, variant=variant, extra=extra, threads=threads, precision="f64", bounds=False)
@@ -326,13 +330,28 @@ def truth_report(cam, sc, up, semantic=True, variant="sr", extra=None, threads=0
 
     items = [(n, out_g[n], out_o[n], out_t[n], "pixel") for n in ["color", "depth", "opacity"] + (["semantic"] if semantic else ["mask"])]
     items += [("grad " + n, gr_g[n], gr_o[n], gr_t[n], "gauss") for n in gr_o]
+    model = []
+    if atomics_seeds:
+        kw = variant_kwargs(sc, variant, extra)
+        if semantic:
+            kw["semantics_precomp"] = sc["semantics_precomp"]
+        gnp = {n: (v.numpy() if hasattr(v, "numpy") else v) for n, v in up.items()}
+        if not semantic:
+            gnp["semantic"] = None
+        for seed in atomics_seeds:
+            model.append(O.backward(st_o, cam, sc["means3D"], gnp, median_rule="forward", fp32_atomics_seed=int(seed), **kw))
     for name, g_, o_, t_, per in items:
         shape = np.asarray(g_).shape
         if int(np.prod(shape)) == 0:
             continue
         a_ = tie_allowance(name, st_o, shape, per)
         fl = floor_for(name)
-        rep["tensors"][name] = dict(hip_vs_truth=dist(g_, t_, a_, fl), oracle32_vs_truth=dist(o_, t_, a_, fl), hip_vs_oracle32=dist(g_, o_, a_, fl),
-                                    floor=fl, max_abs_truth=float(np.abs(np.asarray(t_)).max()))
+        e = dict(hip_vs_truth=dist(g_, t_, a_, fl), oracle32_vs_truth=dist(o_, t_, a_, fl), hip_vs_oracle32=dist(g_, o_, a_, fl),
+                 floor=fl, max_abs_truth=float(np.abs(np.asarray(t_)).max()))
+        if model and per == "gauss":
+            ds = [dist(m[name.replace("grad ", "")], t_, a_, fl) for m in model]
+            e["fp32_atomics_model_vs_truth"] = dict(err_over_max=max(d["err_over_max"] for d in ds), elementwise=max(d["elementwise"] for d in ds),
+                                                    seeds=len(ds), per_seed_elementwise=[d["elementwise"] for d in ds])
+        rep["tensors"][name] = e
     st_o.free(); st_t.free()
     return rep

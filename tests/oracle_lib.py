@@ -168,7 +168,7 @@ def forward(cam, means3D, opacities, colors_precomp=None, shs=None, semantics_pr
 
 
 def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_precomp=None, scales=None,
-             rotations=None, cov3D_precomp=None, threads=0, median_rule="reference", bounds=False):
+             rotations=None, cov3D_precomp=None, threads=0, median_rule="reference", bounds=False, fp32_atomics_seed=None):
     """Oracle backward.  grads: dict(color[3,H,W], semantic[K,H,W]|None, depth, median, opacity).
     median_rule: "reference" = the splat the backward re-finds from its reconstructed T (backward.cu:623-626, :854-857);
     "forward" = the splat whose list position the forward recorded (what the HIP product does; identical except where the
@@ -178,6 +178,9 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
     each gradient entry moves when the flagged threshold decisions of the flagged pixels are taken the other way."""
     L = lib(st.precision)
     rt = L.real
+    # fp32_atomics_seed: the per-Gaussian sums are accumulated in fp32 in a seeded random tile order — one of the orders the reference's
+    # (or the HIP kernels') fp32 atomicAdds can arrive in — instead of in double (oracle/hsr_oracle.c hsro_set_accumulation)
+    L.hsro_set_accumulation(C.c_int(0 if fp32_atomics_seed is None else 1), C.c_uint(int(fp32_atomics_seed or 0)))
     L.hsro_set_median_rule(C.c_int({"reference": 0, "forward": 1}[median_rule]))
     if threads:
         L.hsro_set_threads(C.c_int(threads))
@@ -226,6 +229,7 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
                                 overflow_pixels=int(bstruct.overflow_pixels))
     o["median_rule_disagreements"] = int(L.hsro_last_median_rule_disagreements())
     L.hsro_set_median_rule(C.c_int(0))
+    L.hsro_set_accumulation(C.c_int(0), C.c_uint(0))
     return o
 
 

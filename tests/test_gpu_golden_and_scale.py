@@ -220,15 +220,21 @@ def test_compiled_glue_is_loaded():
     assert _C._ext is not None, "diff_gaussian_rasterization._hsr_torch is not built (python hier-slam_amd/csrc/build_torch_ext.py)"
 
 
-def test_radix_binning_path_matches():
+@pytest.mark.parametrize("impl", ["radix", "wave", "block"])
+def test_radix_binning_path_matches(impl):
     """HSR_SORT_IMPL=radix: emission in Gaussian order + stable tile-bit radix passes + per-tile sort (the path images of more
-    than 8192 tiles take) instead of direct tile binning — same sorted keys, values, ranges and offsets, bit for bit."""
+    than 8192 tiles take) instead of direct tile binning — same sorted keys, values, ranges and offsets, bit for bit.
+    HSR_SORT_IMPL=wave / block: the per-tile sort by one wave per tile / by whole workgroups instead of the default two waves per
+    tile (tile_sort_pair_kernel): every tile size class (<= 256, <= 512, <= 1024, <= 2048, beyond) occurs in the four scenes."""
     import subprocess
     import sys
     code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
             "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
-            "for n in ('replica_tree_k26','plain_mask','huge_splats','deep_tiles_3000')];print('ok')")
-    env = dict(os.environ, HSR_SORT_IMPL="radix")
+            "for n in ('replica_tree_k26','plain_mask','huge_splats','deep_tiles_3000')];"
+            # screen-filling splats: every tile holds (nearly) all P entries, one scene per size class of the per-tile sort and its edges
+            "[_compare(*scenes.build(64,48,P,3,seed=P,kind='aniso',scale_mult=40.0), True, 'sr', None) for P in (60,128,129,250,257,500,513,800,1024,1025,1500,2100)];"
+            "print('ok')")
+    env = dict(os.environ, HSR_SORT_IMPL=impl)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

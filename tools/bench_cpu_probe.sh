@@ -13,7 +13,7 @@ PY
 for i in 1 2 3 4 5 6; do
 python - <<'PY'
 import subprocess, json, sys, os
-r = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline"] + (["--no-pin"] if os.environ.get("NOPIN") else []), capture_output=True, text=True)
+r = subprocess.run([sys.executable, "bench.py", "--no-workloads", "--no-cpu-baseline"] + (["--no-pin"] if os.environ.get("NOPIN") else []), capture_output=True, text=True)
 d = json.loads(r.stdout.strip().splitlines()[-1])
 print(round(d["value"], 1), round(d["ms_per_step"], 4), d["host"])
 PY

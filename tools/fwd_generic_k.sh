@@ -5,7 +5,7 @@ python -m pytest tests/test_gpu_parity.py -m gpu -q -k "k33 or k40 or k74 or k75
 for impl in default wide; do
   for K in 27 28 32 33 43 48 49 60 64 65 75 80 81; do
     if [ $impl = wide ]; then export HSR_FWD_IMPL=wide; else unset HSR_FWD_IMPL; fi
-    python bench.py --no-cpu-baseline --steps 30 --warmup 5 --K $K 2>/dev/null | python -c "
+    python bench.py --no-workloads --no-cpu-baseline --steps 30 --warmup 5 --K $K 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$impl K=$K', round(d['value'],1), 'fwd_render', d['stages_ms']['fwd_render'])"
   done

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "k74 or k75 or k76" 2>&1 | tail -2
 for pf in 1 0; do
   for cfg in "--P 500000 --K 74" "--P 2000000 --K 74 --width 1920 --height 1080"; do
-    HSR_FWD_PF=$pf python bench.py --no-cpu-baseline --steps 30 --warmup 5 $cfg 2>/dev/null | python -c "
+    HSR_FWD_PF=$pf python bench.py --no-workloads --no-cpu-baseline --steps 30 --warmup 5 $cfg 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); c=d['config']
 print('pf=$pf', c['P'], c['K'], c['width'], '%.1f renders/s' % d['value'], 'fwd_render', d['stages_ms']['fwd_render'])"

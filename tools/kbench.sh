@@ -1,5 +1,5 @@
 set -e
-for k in 74 102; do python bench.py --no-cpu-baseline --steps 30 --warmup 5 --P 500000 --K $k > gpurun_out/k$k.json; done
+for k in 74 102; do python bench.py --no-workloads --no-cpu-baseline --steps 30 --warmup 5 --P 500000 --K $k > gpurun_out/k$k.json; done
 python - <<'PY'
 import json
 for k in (74,102):

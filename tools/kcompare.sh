@@ -2,7 +2,7 @@
 for k in 33 40 60 74 90 102 124; do
   for impl in wide valu; do
     if [ $impl = valu ]; then export HSR_FWD_IMPL=valu; else unset HSR_FWD_IMPL; fi
-    python bench.py --no-cpu-baseline --steps 15 --warmup 3 --P 500000 --K $k > gpurun_out/kc.json
+    python bench.py --no-workloads --no-cpu-baseline --steps 15 --warmup 3 --P 500000 --K $k > gpurun_out/kc.json
     python -c "import json;d=json.load(open('gpurun_out/kc.json'));print('K=$k $impl fwd_render %.3f ms  bwd_render %.3f' % (d['stages_ms']['fwd_render'], d['stages_ms']['bwd_render']))"
   done
 done

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/ktrace_$1
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python bench.py --no-workloads --steps 10 --warmup 3 --no-cpu-baseline --no-profile > $OUT/log.txt 2>&1
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv,sys

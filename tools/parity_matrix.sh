@@ -2,7 +2,7 @@
 # bench.py WITH its oracle leg (cpu_baseline + parity at the configuration's own size) over the SURVEY §8(d) matrix -> gpurun_out/parity_matrix.jsonl
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/parity_matrix.jsonl; : > $out
-run() { python bench.py --steps 20 --warmup 5 "$@" >> $out 2>/dev/null; echo "done $*"; }
+run() { python bench.py --no-workloads --steps 20 --warmup 5 "$@" >> $out 2>/dev/null; echo "done $*"; }
 run --P 500000 --K 26
 run --P 500000 --K 26 --kind aniso
 run --P 500000 --K 16

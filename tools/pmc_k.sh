@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE"; do
   n=$(echo "$set" | cut -d' ' -f1)
   rm -rf gpurun_out/pmck_$n
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmck_$n -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --K $K > gpurun_out/pmck_$n.log 2>&1 || echo "pass $n failed"
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmck_$n -- python bench.py --no-workloads --steps 3 --warmup 2 --no-cpu-baseline --no-profile --K $K > gpurun_out/pmck_$n.log 2>&1 || echo "pass $n failed"
 done
 python - <<'PY'
 import csv, collections, glob

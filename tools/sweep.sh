@@ -4,7 +4,7 @@ set -e
 tag=${1:-r01}
 out=gpurun_out/sweep_${tag}.jsonl
 mkdir -p gpurun_out; : > $out
-run() { python bench.py --no-cpu-baseline --steps 30 --warmup 5 "$@" >> $out; echo "done $*"; }
+run() { python bench.py --no-workloads --no-cpu-baseline --steps 30 --warmup 5 "$@" >> $out; echo "done $*"; }
 run --P 100000 --K 26
 run --P 300000 --K 26
 run --P 500000 --K 26

@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 rm -f gpurun_out/tail_sweep.jsonl
 for rows in 27 28 34 35 40 41 42 43 44 46 48 54 55 56; do
   H=$((rows * 16)); P=$((500000 * rows / 43))
-  python bench.py --height $H --P $P --steps 60 --warmup 10 --no-cpu-baseline >> gpurun_out/tail_sweep.jsonl 2>/dev/null || echo "rows $rows failed"
+  python bench.py --no-workloads --height $H --P $P --steps 60 --warmup 10 --no-cpu-baseline >> gpurun_out/tail_sweep.jsonl 2>/dev/null || echo "rows $rows failed"
 done
 python - <<'PY'
 import json

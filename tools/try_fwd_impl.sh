@@ -9,5 +9,5 @@ for n in ('replica_tree_k26','scannet_tree_k16','generic_k5_white_bg','plain_mas
     cam,sc,up = scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)
     _compare(cam,sc,up,sem,var,None); print('ok', n)
 PY
-python bench.py --no-cpu-baseline --steps 30 --warmup 5 > gpurun_out/try_fwd.json && python -c "
+python bench.py --no-workloads --no-cpu-baseline --steps 30 --warmup 5 > gpurun_out/try_fwd.json && python -c "
 import json;d=json.load(open('gpurun_out/try_fwd.json'));print(round(d['value'],1), {a:round(b,3) for a,b in d['stages_ms'].items()})"

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-run() { python bench.py --no-cpu-baseline --steps 30 --warmup 5 "$@" 2>/dev/null | python -c "
+run() { python bench.py --no-workloads --no-cpu-baseline --steps 30 --warmup 5 "$@" 2>/dev/null | python -c "
 import json,sys,os
 d=json.loads(sys.stdin.readline()); c=d['config']
 print(os.environ.get('HSR_BWD_WIDE_FIRST','-'), os.environ.get('HSR_BWD_WIDE_CHUNK','-'), c['P'], c['K'], c['width'], '%.1f renders/s' % d['value'], 'bwd_render', d['stages_ms']['bwd_render'])"; }
