@@ -269,20 +269,13 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
             const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
-            // raw moments of the row (sums over the four groups' slots) -> the reference's sums (backward.cu:648-660, :887-893):
-            //   dL_dmean2D.x = kx (2 A' Sx + B' Sy), .y = ky (2 C' Sy + B' Sx)   (A', B', C': the pre-scaled conic of the staged record)
-            //   dL_dconic.{x,y,w} = -0.5 {Sxx, Sxy, Syy};  columns 5, 6 (opacity, median depth) pass through
-            const int ja = s_cj[wv][row];
-            const float4 gj = s_ent[3 * ja];
-            const float cxj = s_ent[3 * ja + 2].x;
-            const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
-            const float4 sa = *reinterpret_cast<const float4*>(u7 + row * 32 + ca * 4);
-            const float4 sb = *reinterpret_cast<const float4*>(u7 + row * 32 + cb * 4);
+            // sums over the four groups' slots -> the reference's sums (backward.cu:648-660, :887-893):
+            //   dL_dmean2D.{x,y} = 2 {kx, ky} x the per-pixel combined sums;  dL_dconic.{x,y,w} = -0.5 {Sxx, Sxy, Syy} (raw moments of q);
+            //   columns 5, 6 (opacity, median depth) pass through
+            const float4 sa = *reinterpret_cast<const float4*>(u7 + row * 32 + vi * 4);
             const float ta = (sa.x + sa.y) + (sa.z + sa.w);
-            const float tb = (sb.x + sb.y) + (sb.z + sb.w);
-            const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
-            const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
-            const float val = fmaf(wb, tb, wa * ta);
+            const float wa = vi == 0 ? 2.0f * kx : (vi == 1 ? 2.0f * ky : (vi <= 4 ? -0.5f : 1.0f));
+            const float val = wa * ta;
             const uint32_t base = s_cid[wv][row] + (uint32_t)vi;
             if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
@@ -334,7 +327,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
             s_id[t] = id_cur;
             s_ent[3 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
             s_ent[3 * t + 1] = make_float4(p_r, p_g, p_b, p_d);
-            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, 0.f, 0.f);
+            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, (-0.5f * HSR_LOG2E) * p_co.y, 0.f);   // C', opacity, B' / 2
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
@@ -380,7 +373,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 const float4* ent = &s_ent[3 * j];
                 const float4 g = ent[0];
                 const float4 cd = ent[1];
-                const float2 co = *reinterpret_cast<const float2*>(&ent[2]);
+                const float4 co4 = ent[2];
+                const float2 co = make_float2(co4.x, co4.y);
+                const float hB = co4.z;   // B' / 2
                 asm volatile("" ::"v"(cd.x), "v"(cd.y), "v"(cd.z), "v"(cd.w));
                 const float dx = g.x - pfx, dy = g.y - pfy;
                 const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
@@ -412,13 +407,16 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
                 const float Gs = active ? G : 0.f;
                 const float gda = Gs * dL_dalpha;
                 const float q = co.y * gda;
-                // The five geometry sums are linear in the RAW moments of q over the pixels — sum q dx, q dy, q dx^2, q dx dy, q dy^2 —
-                // with coefficients that only depend on the splat (conic, 0.5 W, 0.5 H): the lanes reduce the raw moments (5
-                // multiplies instead of 14 instructions per iteration) and the coefficients are applied once per (chunk row, value)
-                // when the row is emitted (flush).
+                // The three conic sums are the RAW second moments of q over the pixels (sum q dx^2, q dx dy, q dy^2) times -0.5, and the
+                // mean2D sums carry the constant factors 2 kx / 2 ky: those coefficients are applied once per (chunk row, value) when
+                // the row is emitted (flush), not per pixel.
                 float v[SB_NV];
-                v[0] = q * dx;
-                v[1] = q * dy;
+                // dL_dmean2D: the two terms combined PER PIXEL, as the reference does (backward.cu:887-888).  Round 2 summed the raw moments
+                // q dx and q dy and combined them at emission; for elongated splats A' dx and B' dy / 2 largely cancel, and cancelling AFTER
+                // the fp32 sums over the pixels cost up to 15x the error in these two sums (found with the truth build of the oracle:
+                // tests/test_gpu_truth.py) — which the per-Gaussian chain then amplifies into dL_dscales / dL_dmeans3D.
+                v[0] = q * fmaf(g.z, dx, hB * dy);    // (A' dx + B' dy / 2): x kx * 2 at emission
+                v[1] = q * fmaf(co.x, dy, hB * dx);   // (C' dy + B' dx / 2)
                 v[2] = q * dxx;
                 v[3] = q * dxy;
                 v[4] = q * dyy;
@@ -531,17 +529,10 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
             const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
-            const int ja = s_cj[wv][row];
-            const float4 gj = s_ent[3 * ja];
-            const float cxj = s_ent[3 * ja + 2].x;
-            const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
-            const float4 sa = *reinterpret_cast<const float4*>(u7 + row * 32 + ca * 4);
-            const float4 sb = *reinterpret_cast<const float4*>(u7 + row * 32 + cb * 4);
+            const float4 sa = *reinterpret_cast<const float4*>(u7 + row * 32 + vi * 4);
             const float ta = (sa.x + sa.y) + (sa.z + sa.w);
-            const float tb = (sb.x + sb.y) + (sb.z + sb.w);
-            const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
-            const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
-            const float val = fmaf(wb, tb, wa * ta);
+            const float wa = vi == 0 ? 2.0f * kx : (vi == 1 ? 2.0f * ky : (vi <= 4 ? -0.5f : 1.0f));
+            const float val = wa * ta;
             const uint32_t base = s_cid[wv][row] + (uint32_t)vi;
             if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
@@ -591,7 +582,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
             s_id[t] = id_cur;
             s_ent[3 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
             s_ent[3 * t + 1] = make_float4(p_r, p_g, p_b, p_d);
-            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, 0.f, 0.f);
+            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, (-0.5f * HSR_LOG2E) * p_co.y, 0.f);   // C', opacity, B' / 2
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
@@ -634,7 +625,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                 const float4* ent = &s_ent[3 * j];
                 const float4 g = ent[0];
                 const float4 cd = ent[1];
-                const float2 co = *reinterpret_cast<const float2*>(&ent[2]);
+                const float4 co4 = ent[2];
+                const float2 co = make_float2(co4.x, co4.y);
+                const float hB = co4.z;   // B' / 2
                 asm volatile("" ::"v"(cd.x), "v"(cd.y), "v"(cd.z), "v"(cd.w));
                 const float dx = g.x - pfx, dy = g.y - pfy;
                 const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
@@ -656,8 +649,12 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
                 const float gda = Gs * dL_dalpha;
                 const float q = co.y * gda;
                 float v[SB_NV];   // raw moments of q; the splat's coefficients are applied at emission (see render_bwd_sub_kernel)
-                v[0] = q * dx;
-                v[1] = q * dy;
+                // dL_dmean2D: the two terms combined PER PIXEL, as the reference does (backward.cu:887-888).  Round 2 summed the raw moments
+                // q dx and q dy and combined them at emission; for elongated splats A' dx and B' dy / 2 largely cancel, and cancelling AFTER
+                // the fp32 sums over the pixels cost up to 15x the error in these two sums (found with the truth build of the oracle:
+                // tests/test_gpu_truth.py) — which the per-Gaussian chain then amplifies into dL_dscales / dL_dmeans3D.
+                v[0] = q * fmaf(g.z, dx, hB * dy);    // (A' dx + B' dy / 2): x kx * 2 at emission
+                v[1] = q * fmaf(co.x, dy, hB * dx);   // (C' dy + B' dx / 2)
                 v[2] = q * dxx;
                 v[3] = q * dxy;
                 v[4] = q * dyy;
@@ -855,17 +852,10 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
 #pragma unroll
         for (int pass = 0; pass < (BASE ? 2 : 0); pass++) {
             const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
-            const int ja = s_cj[wv][row];
-            const float4 gj = s_ent[3 * ja];
-            const float cxj = s_ent[3 * ja + 2].x;
-            const int ca = vi, cb = vi == 0 ? 1 : 0;   // second moment only for the two mean2D columns
-            const float4 sa = *reinterpret_cast<const float4*>(u7 + row * 32 + ca * 4);
-            const float4 sb = *reinterpret_cast<const float4*>(u7 + row * 32 + cb * 4);
+            const float4 sa = *reinterpret_cast<const float4*>(u7 + row * 32 + vi * 4);
             const float ta = (sa.x + sa.y) + (sa.z + sa.w);
-            const float tb = (sb.x + sb.y) + (sb.z + sb.w);
-            const float wa = vi == 0 ? 2.0f * gj.z * kx : (vi == 1 ? 2.0f * cxj * ky : (vi <= 4 ? -0.5f : 1.0f));
-            const float wb = vi == 0 ? gj.w * kx : (vi == 1 ? gj.w * ky : 0.0f);
-            const float val = fmaf(wb, tb, wa * ta);
+            const float wa = vi == 0 ? 2.0f * kx : (vi == 1 ? 2.0f * ky : (vi <= 4 ? -0.5f : 1.0f));
+            const float val = wa * ta;
             const uint32_t base = s_cid[wv][row] + (uint32_t)vi;
             if (vi < SB_NV && row < nrows && val != 0.f && !(a.debug_flags & 1)) atomicAdd(a.grow + base, val);
         }
@@ -915,7 +905,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
             s_id[t] = id_cur;
             s_ent[3 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
             s_ent[3 * t + 1] = make_float4(p_r, p_g, p_b, p_d);
-            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, 0.f, 0.f);
+            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, (-0.5f * HSR_LOG2E) * p_co.y, 0.f);   // C', opacity, B' / 2
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
@@ -958,7 +948,9 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
                 const float4* ent = &s_ent[3 * j];
                 const float4 g = ent[0];
                 const float4 cd = ent[1];
-                const float2 co = *reinterpret_cast<const float2*>(&ent[2]);
+                const float4 co4 = ent[2];
+                const float2 co = make_float2(co4.x, co4.y);
+                const float hB = co4.z;   // B' / 2
                 asm volatile("" ::"v"(cd.x), "v"(cd.y), "v"(cd.z), "v"(cd.w));
                 const float dx = g.x - pfx, dy = g.y - pfy;
                 const float dxx = dx * dx, dxy = dx * dy, dyy = dy * dy;
@@ -985,8 +977,12 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
                 const float gda = Gs * dL_dalpha;
                 const float q = co.y * gda;
                 float v[SB_NV];   // raw moments of q; the splat's coefficients are applied at emission (see render_bwd_sub_kernel)
-                v[0] = q * dx;
-                v[1] = q * dy;
+                // dL_dmean2D: the two terms combined PER PIXEL, as the reference does (backward.cu:887-888).  Round 2 summed the raw moments
+                // q dx and q dy and combined them at emission; for elongated splats A' dx and B' dy / 2 largely cancel, and cancelling AFTER
+                // the fp32 sums over the pixels cost up to 15x the error in these two sums (found with the truth build of the oracle:
+                // tests/test_gpu_truth.py) — which the per-Gaussian chain then amplifies into dL_dscales / dL_dmeans3D.
+                v[0] = q * fmaf(g.z, dx, hB * dy);    // (A' dx + B' dy / 2): x kx * 2 at emission
+                v[1] = q * fmaf(co.x, dy, hB * dx);   // (C' dy + B' dx / 2)
                 v[2] = q * dxx;
                 v[3] = q * dxy;
                 v[4] = q * dyy;

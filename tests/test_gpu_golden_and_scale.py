@@ -220,7 +220,7 @@ def test_compiled_glue_is_loaded():
     assert _C._ext is not None, "diff_gaussian_rasterization._hsr_torch is not built (python hier-slam_amd/csrc/build_torch_ext.py)"
 
 
-@pytest.mark.parametrize("impl", ["radix", "wave", "block"])
+@pytest.mark.parametrize("impl", ["radix", "wave", "block", "default"])
 def test_radix_binning_path_matches(impl):
     """HSR_SORT_IMPL=radix: emission in Gaussian order + stable tile-bit radix passes + per-tile sort (the path images of more
     than 8192 tiles take) instead of direct tile binning — same sorted keys, values, ranges and offsets, bit for bit.
