@@ -242,6 +242,10 @@ def gpu_numa_cpus(n_local):
 # sets config.h:18, the stress configuration): (width, height, P, K, kind, tag)
 EXTRA_WORKLOADS = [
     (1200, 680, 100000, 26, "slam", "100k"),
+    # the same with the opt-in non-blocking forward (diff_gaussian_rasterization.set_async_forward): at this size the blocking
+    # read-back of num_rendered, not the device, sets the step time
+    (1200, 680, 100000, 26, "slam", "100k, non-blocking forward (opt-in)"),
+    (1200, 680, 500000, 26, "slam", "500k (headline), non-blocking forward (opt-in)"),
     (1200, 680, 300000, 26, "slam", "300k (BASELINE.json configs[1]: ~300k Gaussians)"),
     (1200, 680, 2000000, 26, "slam", "2M"),
     (1200, 680, 500000, 16, "slam", "K=16 (ScanNet NYU40 4-level tree)"),
@@ -404,6 +408,7 @@ def main():
     ap.add_argument("--no-workloads", action="store_true", help="N = 1: only the headline workload, not the rest of the north star's list")
     ap.add_argument("--workload-steps", type=int, default=20, help="timed steps of each extra workload (at least 20)")
     ap.add_argument("--dense-exchange", action="store_true", help="N > 1: all-reduce every gradient row instead of the visible union")
+    ap.add_argument("--async-forward", action="store_true", help="opt-in non-blocking forward for the main workload too (diff_gaussian_rasterization.set_async_forward)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
@@ -463,7 +468,12 @@ def main():
         # region ends with both drained.  As at N = 1 there is no optimizer inside a step.
         exch = GradientExchange({"raster." + n: wl.leaf[n] for n in wl.names}, dev, depth=2, sparse=not args.dense_exchange)
     wl.exchange = exch
+    if args.async_forward:
+        import diff_gaussian_rasterization as dgr
+        dgr.set_async_forward(True)
     res = wl.run(args.steps, args.warmup, profile=not args.no_profile, lib=_C._lib)
+    if args.async_forward:
+        dgr.set_async_forward(False)
     elapsed = res["elapsed"]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -486,7 +496,8 @@ def main():
                        "parallelism": ("keyframe-parallel x%d: one keyframe per rank per step; gradients are views of the exchange bucket, "
                                        "%s all-reduce, 2 buckets in flight (all-reduce of step i overlaps render i+1)"
                                        % (world, "visibility-sparse" if not args.dense_exchange else "dense")) if world > 1 else "single GPU",
-                       "api": "diff_gaussian_rasterization.GaussianRasterizer_semantic (torch autograd) -> C ABI"},
+                       "api": "diff_gaussian_rasterization.GaussianRasterizer_semantic (torch autograd) -> C ABI"
+                              + (", non-blocking forward (opt-in)" if args.async_forward else "")},
         }
         if exch is not None:
             out["exchange"] = exch.stats()
@@ -511,12 +522,18 @@ def main():
         stress = None
         if world == 1 and not args.no_workloads:
             out["workloads"] = []
+            import diff_gaussian_rasterization as dgr
             for (w_, h_, p_, k_, kind_, tag) in EXTRA_WORKLOADS:
-                if (w_, h_, p_, k_, kind_) == (W, H, P, K, args.kind):
+                ahead = "non-blocking" in tag
+                if (w_, h_, p_, k_, kind_) == (W, H, P, K, args.kind) and not ahead:
                     continue
                 wl.release()
                 wl = Workload(dev, w_, h_, p_, k_, kind_, 0, 1)
-                r2 = wl.run(max(20, args.workload_steps), 5, profile=not args.no_profile, lib=_C._lib)
+                dgr.set_async_forward(ahead)
+                try:
+                    r2 = wl.run(max(20, args.workload_steps), 5, profile=not args.no_profile, lib=_C._lib)
+                finally:
+                    dgr.set_async_forward(False)
                 e = {"workload": wl.describe(), "tag": tag, "renders_s": r2["steps"] / r2["elapsed"], "ms_per_step": 1e3 * r2["elapsed"] / r2["steps"],
                      "steps": r2["steps"], "visible": r2["V"], "num_rendered": r2["R"],
                      "host_blocked_on_device_ms_per_step": round(r2["host_wait_ms"], 4)}

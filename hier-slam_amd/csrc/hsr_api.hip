@@ -110,6 +110,18 @@ thread_local PinnedCounter* g_pc = nullptr;      // the current call's slot (set
 #define g_counter_seq (g_pc->seq)
 #define g_counter_event (g_pc->event)
 
+// Non-blocking forward (hsr_forward_arm_async): the count lands in a slot of a per-device ring of host-mapped words that is
+// process-wide — the ticket may be resolved on another thread (autograd's backward thread) than the one that called the forward.
+struct AsyncRing {
+    uint32_t* host = nullptr;
+    uint32_t* dev = nullptr;
+    uint32_t seq = 0;
+};
+constexpr int HSR_ASYNC_SLOTS = 256;   // forwards in flight per device before a slot is reused
+std::mutex g_async_mu;
+AsyncRing g_async_ring[64];
+thread_local hsr_ticket* g_armed_ticket = nullptr;
+
 // ---- optional per-stage timing with HIP events (hsr_profile_*) ----
 struct StageEvents {
     int stage;
@@ -194,9 +206,30 @@ int read_counter_end(uint32_t* host_out)
 }
 // Direct-binning path: bin_hist_kernel's last workgroup stores {num_rendered, seq} into the host-mapped buffer itself (no copy
 // kernel, no event): the host polls the sequence number.  A launch that never completes is caught by a stream query after 10 s.
-int poll_counter(uint32_t seq, hipStream_t stream, uint32_t* host_out)
+int poll_counter(uint32_t seq, hipStream_t stream, uint32_t* host_out, volatile uint32_t* slot = nullptr)
 {
     const auto t0 = std::chrono::steady_clock::now();
+    if (slot) {   // a ring slot of the non-blocking forward (may be resolved on another thread: no per-thread back-off state)
+        unsigned spins = 0;
+        while (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0xFFFu) == 0) {
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (el > 10.0) {
+                    const hipError_t e = hipStreamSynchronize(stream);
+                    if (e != hipSuccess || __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) != seq) {
+                        hsr_set_error("num_rendered never arrived (%s)", hipGetErrorString(e));
+                        return HSR_ERR_HIP;
+                    }
+                }
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        g_host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *host_out = __atomic_load_n(&slot[0], __ATOMIC_RELAXED);
+        return HSR_OK;
+    }
     // Back-off: the count arrives when the kernels queued in front of it (typically the previous step's backward) have run —
     // a few hundred microseconds in a training loop — and a `pause` loop would hold a core at 100 % for all of it.  Sleep
     // through the first half of the recently observed wait (an average over the last calls), then poll; short waits (< 0.15
@@ -238,9 +271,35 @@ struct FwdIn {
     int* radii;
 };
 
+// a slot of the device's ring for one non-blocking forward
+int ring_slot(uint32_t* seq_out, volatile uint32_t** host_out, uint32_t** dev_out, int* device_out)
+{
+    int d = 0;
+    HSR_HIP_CHECK(hipGetDevice(&d));
+    if (d < 0 || d >= 64) {
+        hsr_set_error("device index %d out of range", d);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    std::lock_guard<std::mutex> lk(g_async_mu);
+    AsyncRing& r = g_async_ring[d];
+    if (!r.host) {
+        HSR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&r.host), HSR_ASYNC_SLOTS * 16, hipHostMallocPortable | hipHostMallocMapped));
+        memset(r.host, 0, HSR_ASYNC_SLOTS * 16);
+        HSR_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.dev), r.host, 0));
+    }
+    uint32_t s = ++r.seq;
+    if (s == 0) s = ++r.seq;
+    const uint32_t idx = s % HSR_ASYNC_SLOTS;
+    *seq_out = s; *host_out = r.host + 4 * idx; *dev_out = r.dev + 4 * idx; *device_out = d;
+    return HSR_OK;
+}
+
 int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, const FwdIn& in, hipStream_t stream)
 {
     const int P = in.P, W = in.W, H = in.H;
+    hsr_ticket* ticket = g_armed_ticket;   // hsr_forward_arm_async: this call may return before num_rendered is known
+    g_armed_ticket = nullptr;
+    if (ticket) memset(ticket, 0, sizeof(*ticket));
     if (P < 0 || W <= 0 || H <= 0) {
         hsr_set_error("invalid sizes P=%d W=%d H=%d", P, W, H);
         return HSR_ERR_INVALID_ARGUMENT;
@@ -327,13 +386,24 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     HsrBinPlan plan{0, 0};
     uint32_t* bin_scratch = reinterpret_cast<uint32_t*>(im.final_T);   // free until the render kernel writes it
     const bool binned = !force_radix && hsr_bin_plan(P, T, (size_t)W * H, &plan);
+    static const bool no_speculation = hsr_ablate_env("HSR_NO_SPECULATION") != nullptr;
+    const bool will_speculate = binned && !no_speculation && !in.debug && binning && binning->ptr && binning->capacity >= 4096;
+    const bool go_async = ticket != nullptr && will_speculate;
     uint32_t seq = 0;
+    volatile uint32_t* slot_host = nullptr;   // non-blocking forward: this call's slot of the device's ring
+    uint32_t* slot_dev = nullptr;
+    int slot_device = 0;
     if (binned) {
-        if ((rc = counter_buffer()) != HSR_OK) return rc;
-        seq = ++g_counter_seq;
-        if (seq == 0) seq = ++g_counter_seq;
+        if (go_async) {
+            if ((rc = ring_slot(&seq, &slot_host, &slot_dev, &slot_device)) != HSR_OK) return rc;
+        } else {
+            if ((rc = counter_buffer()) != HSR_OK) return rc;
+            seq = ++g_counter_seq;
+            if (seq == 0) seq = ++g_counter_seq;
+            slot_dev = g_pinned_dev;
+        }
         StageTimer tm(HSR_STAGE_FWD_DUPLICATE, stream);
-        hsr_launch_bin_count(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, stream, g_pinned_dev, seq);
+        hsr_launch_bin_count(plan, P, radii, tiles_x, tiles_y, g, bin_scratch, im.ranges, stream, slot_dev, seq);
     } else {
         StageTimer tm(HSR_STAGE_FWD_SCAN, stream);
         hsr_launch_scan_block_sums(P, g, stream);
@@ -366,9 +436,8 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
     // The host then waits on an event that completed long ago instead of idling the stream while it wakes up and launches
     // the rest — the reference stalls here on every frame (rasterizer_impl.cu:285), and with a 0.65 ms render the host
     // side (~0.45 ms per fwd+bwd through Python) would otherwise be on the critical path.
-    static const bool no_speculation = hsr_ablate_env("HSR_NO_SPECULATION") != nullptr;
     bool speculated = false;
-    if (binned && !no_speculation && !in.debug && binning && binning->ptr && binning->capacity >= 4096) {
+    if (will_speculate) {
         const BinDevRef ref{static_cast<char*>(binning->ptr), reinterpret_cast<const uint32_t*>(g.counters), binning->capacity};
         BinState none{nullptr, nullptr, nullptr, nullptr, nullptr};
         {
@@ -386,6 +455,16 @@ int forward_impl(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, c
         }
         HSR_HIP_CHECK(hipGetLastError());
         speculated = true;
+    }
+    if (go_async) {
+        // everything is enqueued; the count is read by hsr_forward_end (typically from the backward, when it has long arrived)
+        ticket->seq = seq;
+        ticket->device = slot_device;
+        ticket->slot = slot_host;
+        ticket->binning_base = static_cast<char*>(binning->ptr);
+        ticket->binning_capacity = binning->capacity;
+        ticket->prefiltered = in.prefiltered;
+        return HSR_PENDING;
     }
 
     uint32_t R32 = 0;
@@ -814,6 +893,47 @@ int hsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     hsr_launch_mark_visible(P, means3D, viewmatrix, projmatrix, present, static_cast<hipStream_t>(stream));
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
+}
+
+int hsr_forward_arm_async(hsr_ticket* ticket)
+{
+    if (!ticket) {
+        hsr_set_error("hsr_forward_arm_async: ticket is NULL");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    memset(ticket, 0, sizeof(*ticket));
+    g_armed_ticket = ticket;
+    return HSR_OK;
+}
+
+int hsr_forward_end(hsr_ticket* ticket, int block, void* stream)
+{
+    if (!ticket || ticket->seq == 0 || !ticket->slot) {
+        hsr_set_error("hsr_forward_end: the ticket does not belong to a forward call that ran ahead");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!block && __atomic_load_n(&ticket->slot[1], __ATOMIC_ACQUIRE) != ticket->seq) return HSR_PENDING;
+    uint32_t R32 = 0;
+    int rc;
+    if ((rc = poll_counter(ticket->seq, static_cast<hipStream_t>(stream), &R32, ticket->slot)) != HSR_OK) return rc;
+    if (R32 > 0x7fffffffu) {
+        hsr_set_error("num_rendered %u overflows int", R32);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    ticket->rendered = (int32_t)R32;
+    if (ticket->prefiltered && __atomic_load_n(&ticket->slot[2], __ATOMIC_RELAXED) != 0) {
+        hsr_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    BinState chk;
+    const BinDevRef ref{ticket->binning_base, nullptr, ticket->binning_capacity};
+    if (!hsr_bin_resolve(ref, R32, &chk)) {
+        hsr_set_error("non-blocking forward: num_rendered = %u does not fit the binning buffer (%zu bytes, %zu needed): the output images of "
+                      "that call were filled with NaN; run the forward again with a larger buffer", R32, ticket->binning_capacity,
+                      hsr_required_binning_bytes((int)R32));
+        return HSR_ERR_BUFFER_TOO_SMALL;
+    }
+    return (int)R32;
 }
 
 int hsr_forward(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* image, int P, int D, int M, const float* background,

@@ -163,7 +163,10 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
     const int t = threadIdx.x, wv = t >> 6;
     if (a.bin.base) {   // speculative forward: the list lives where num_rendered says
         BinState bs;
-        if (!hsr_bin_resolve(a.bin, *a.bin.R_dev, &bs)) return;
+        if (!hsr_bin_resolve(a.bin, *a.bin.R_dev, &bs)) {
+            hsr_poison_tile(a, tile, t, BASE, c0, KC);
+            return;
+        }
         a.point_list = bs.vals;
         a.masks = bs.vals_unsorted;
     }

@@ -45,7 +45,10 @@ __global__ void __launch_bounds__(256, 2) render_fwd_wide_kernel(RenderFwdArgs a
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (a.bin.base) {   // speculative forward: the list lives where num_rendered says
         BinState bs;
-        if (!hsr_bin_resolve(a.bin, *a.bin.R_dev, &bs)) return;
+        if (!hsr_bin_resolve(a.bin, *a.bin.R_dev, &bs)) {
+            hsr_poison_tile(a, tile, t, true, 0, a.K);
+            return;
+        }
         a.point_list = bs.vals;
         a.masks = bs.vals_unsorted;
     }

@@ -32,6 +32,27 @@
 __host__ __device__ inline int hsr_tile_grid(int T) { return 8 * ((T + 7) / 8); }
 __device__ __forceinline__ int hsr_block_tile(int b, int T) { return (b & 7) * ((T + 7) >> 3) + (b >> 3); }
 
+// The speculative forward found its binning buffer too small for num_rendered (hsr_bin_resolve failed): nothing can be rendered.  A
+// blocking hsr_forward* call runs the kernels again with a grown buffer; a NON-blocking one (hsr_forward_arm_async) cannot, so the tile
+// kernel leaves NaN in every output it owns — whatever is computed from them before hsr_forward_end reports the overflow is visibly
+// invalid instead of silently wrong.  Thread t of the tile's workgroup: pixel (t & 15, t >> 4); channels [c0, c0 + nsem) of the
+// semantic map; `base`: also colour / depth / median depth / opacity (/ mask).
+__device__ __forceinline__ void hsr_poison_tile(const RenderFwdArgs& a, int tile, int t, bool base, int c0, int nsem)
+{
+    const int tiles_x = (a.W + HSR_TILE_X - 1) / HSR_TILE_X;
+    const int px = (tile % tiles_x) * HSR_TILE_X + (t & 15), py = (tile / tiles_x) * HSR_TILE_Y + (t >> 4);
+    if (px >= a.W || py >= a.H) return;
+    const size_t N = (size_t)a.W * a.H, pix = (size_t)a.W * py + px;
+    const float nan = __uint_as_float(0x7fc00000u);
+    if (base) {
+        a.out_color[pix] = nan; a.out_color[N + pix] = nan; a.out_color[2 * N + pix] = nan;
+        a.out_depth[pix] = nan; a.out_median_depth[pix] = nan; a.out_opacity[pix] = nan;
+        if (a.out_mask) a.out_mask[pix] = nan;
+    }
+    if (a.out_semantic)
+        for (int c = c0; c < c0 + nsem && c < a.K; c++) a.out_semantic[(size_t)c * N + pix] = nan;
+}
+
 struct TileGeom {
     int tx, ty;        // tile coordinates
     int px, py;        // this lane's pixel

@@ -12,6 +12,7 @@
 
 #include <c10/core/DeviceGuard.h>
 
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -71,12 +72,15 @@ std::map<std::tuple<int, int64_t, int64_t, int64_t>, int64_t> g_binning_hint;
 
 using OptT = c10::optional<at::Tensor>;
 
-// -> (rendered, color, aux (semantic map | mask), depth, median_depth, opacity, radii, geomBuffer, binningBuffer, imgBuffer)
-std::tuple<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor>
+// -> (rendered, color, aux (semantic map | mask), depth, median_depth, opacity, radii, geomBuffer, binningBuffer, imgBuffer, ticket)
+// run_ahead: non-blocking forward (include/hsr_rasterizer.h hsr_forward_arm_async): when the call ran ahead, rendered == HSR_PENDING and
+// `ticket` holds the bytes of its hsr_ticket (resolved with forward_end); otherwise `ticket` is empty.
+std::tuple<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, py::bytes>
 forward_common(bool semantic, const OptT& background, const at::Tensor& means3D, const OptT& colors, const OptT& semantics,
                const OptT& opacity, const OptT& scales, const OptT& rotations, double scale_modifier, const OptT& cov3D_precomp,
                const OptT& viewmatrix, const OptT& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height,
-               int64_t image_width, const OptT& sh, int64_t degree, const OptT& campos, bool prefiltered, bool debug, int64_t stream)
+               int64_t image_width, const OptT& sh, int64_t degree, const OptT& campos, bool prefiltered, bool debug, int64_t stream,
+               bool run_ahead)
 {
     TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");   // rasterize_points.cu:60-62
     TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization: tensors must live on a HIP device (got ", means3D.device(),
@@ -111,7 +115,8 @@ forward_common(bool semantic, const OptT& background, const at::Tensor& means3D,
         }
         geom = at::empty({(int64_t)hsr_required_geometry_bytes((int)P)}, bopt);
         img = at::empty({(int64_t)hsr_required_image_bytes((int)W, (int)H)}, bopt);
-        binning = at::empty({(int64_t)hsr_required_binning_bytes((int)(hint + hint / 4) + 1024)}, bopt);
+        // a call that runs ahead cannot grow the buffer afterwards: twice the last count instead of a quarter more
+        binning = at::empty({(int64_t)hsr_required_binning_bytes((int)(run_ahead ? 2 * hint : hint + hint / 4) + 1024)}, bopt);
     }
     const int64_t M = (sh.has_value() && sh->defined() && sh->numel() != 0) ? sh->size(1) : 0;
     const at::Tensor bg_ = prep(background, dev), m3_ = prep(means3D, dev), sh_ = prep(sh, dev), col_ = prep(colors, dev);
@@ -119,6 +124,8 @@ forward_common(bool semantic, const OptT& background, const at::Tensor& means3D,
     const at::Tensor op_ = prep(opacity, dev), sc_ = prep(scales, dev), rot_ = prep(rotations, dev), cov_ = prep(cov3D_precomp, dev);
     const at::Tensor vm_ = prep(viewmatrix, dev), pm_ = prep(projmatrix, dev), cp_ = prep(campos, dev);
     hsr_buffer gb = as_buffer(geom), bb = as_buffer(binning), ib = as_buffer(img);
+    hsr_ticket tk;
+    if (run_ahead && P) hsr_forward_arm_async(&tk);
     int rc;
     if (semantic)
         rc = hsr_forward_semantic(&gb, &bb, &ib, (int)P, (int)degree, (int)M, (int)K, ptr(bg_), (int)W, (int)H, ptr(m3_), ptr(sh_),
@@ -131,12 +138,26 @@ forward_common(bool semantic, const OptT& background, const at::Tensor& means3D,
                          ptr(sc_), (float)scale_modifier, ptr(rot_), ptr(cov_), ptr(vm_), ptr(pm_), ptr(cp_), (float)tan_fovx,
                          (float)tan_fovy, prefiltered ? 1 : 0, ptr(out_color), ptr(out_depth), ptr(out_median), ptr(out_opacity),
                          ptr(out_aux), ptr<int>(radii), debug ? 1 : 0, reinterpret_cast<void*>(stream));
+    if (rc == HSR_PENDING)
+        return std::make_tuple((int64_t)rc, out_color, out_aux, out_depth, out_median, out_opacity, radii, geom, binning, img,
+                               py::bytes(reinterpret_cast<const char*>(&tk), sizeof(tk)));
     if (rc < 0) fail(rc, semantic ? "rasterize_gaussians_semantic" : "rasterize_gaussians");
     if (P) {
         std::lock_guard<std::mutex> lock(g_hint_mutex);
         g_binning_hint[key] = rc;
     }
-    return std::make_tuple((int64_t)rc, out_color, out_aux, out_depth, out_median, out_opacity, radii, geom, binning, img);
+    return std::make_tuple((int64_t)rc, out_color, out_aux, out_depth, out_median, out_opacity, radii, geom, binning, img, py::bytes());
+}
+
+// resolves a ticket of a forward call that ran ahead -> (return code of hsr_forward_end, num_rendered as far as known, error text)
+std::tuple<int64_t, int64_t, std::string> forward_end(const py::bytes& ticket, bool block, int64_t stream)
+{
+    const std::string raw = ticket;
+    TORCH_CHECK(raw.size() == sizeof(hsr_ticket), "forward_end: not a ticket");
+    hsr_ticket tk;
+    memcpy(&tk, raw.data(), sizeof(tk));
+    const int rc = hsr_forward_end(&tk, block ? 1 : 0, reinterpret_cast<void*>(stream));
+    return std::make_tuple((int64_t)rc, (int64_t)tk.rendered, std::string(rc < 0 && rc != HSR_PENDING ? hsr_last_error() : ""));
 }
 
 // -> (dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
@@ -223,6 +244,7 @@ int64_t binning_hint(int64_t device_index, int64_t P, int64_t W, int64_t H, int6
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.def("forward_common", &forward_common);
+    m.def("forward_end", &forward_end);
     m.def("backward_common", &backward_common);
     m.def("binning_hint", &binning_hint, "read (-1), set (>= 0) or forget (-2) the binning size hint of (device, P, W, H)");
 }

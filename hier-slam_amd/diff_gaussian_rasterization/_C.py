@@ -29,6 +29,16 @@ class _HsrBuffer(C.Structure):
 _GROW_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 
+class _Ticket(C.Structure):
+    """hsr_ticket (include/hsr_rasterizer.h): a forward call that returned before num_rendered was known"""
+    _fields_ = [("seq", C.c_uint32), ("device", C.c_int32), ("slot", C.c_void_p), ("binning_base", C.c_void_p),
+                ("binning_capacity", C.c_size_t), ("prefiltered", C.c_int32), ("rendered", C.c_int32)]
+
+
+HSR_PENDING = -100
+HSR_ERR_BUFFER_TOO_SMALL = -2
+
+
 class _StateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "geom_depths", "geom_means2D", "geom_conic_opacity", "geom_cov3D", "geom_rgb", "geom_clamped",
@@ -87,6 +97,10 @@ def _load():
     lib.hsr_profile_read.argtypes = [vp, ci]
     lib.hsr_get_state_layout.restype = ci
     lib.hsr_get_state_layout.argtypes = [ci, ci, ci, ci, C.POINTER(_StateLayout)]
+    lib.hsr_forward_arm_async.restype = ci
+    lib.hsr_forward_arm_async.argtypes = [C.POINTER(_Ticket)]
+    lib.hsr_forward_end.restype = ci
+    lib.hsr_forward_end.argtypes = [C.POINTER(_Ticket), ci, vp]
     return lib
 
 
@@ -148,6 +162,104 @@ class _HintMap(dict):
 
 
 _binning_hint = _HintMap()
+
+# Non-blocking forward (opt-in).  The reference's forward stalls host and stream on a 4-byte read-back of num_rendered in every frame
+# (rasterizer_impl.cu:285 / :548); by default this glue also returns num_rendered as an int, i.e. waits for the device to have counted.
+# set_async_forward(True): a forward whose inputs need gradients, on a (device, P, W, H) that has rendered before, enqueues ALL its
+# kernels into a binning buffer sized for TWICE the previous count and returns at once; num_rendered comes back as a LazyRendered
+# that resolves itself when it is first used as a number (the autograd backward does: by then the count has long been written).
+# The price, and the reason this is not the default: should num_rendered more than double from one frame to the next, the buffer is
+# too small, nothing could be rendered, the outputs of that call are all NaN, and resolving the count raises — the step has to be
+# repeated (the next call's buffer is sized from the count that did not fit).
+_async_forward = os.environ.get("HSR_ASYNC_FORWARD", "") == "1"
+
+
+def set_async_forward(on):
+    """enable / disable the non-blocking forward (see above); returns the previous setting"""
+    global _async_forward
+    prev, _async_forward = _async_forward, bool(on)
+    return prev
+
+
+class LazyRendered:
+    """num_rendered of a forward call that ran ahead of the device: an int-like that fetches the count (and checks that it fitted
+    the binning buffer) the first time it is used as a number"""
+    __slots__ = ("_ticket", "_value", "_key", "_stream")
+
+    def __init__(self, ticket, key, stream):
+        self._ticket, self._value, self._key, self._stream = ticket, None, key, stream
+
+    def ready(self):
+        """has the device written the count yet? (never blocks)"""
+        return self._value is not None or self._end(False) is not None
+
+    def _end(self, block):
+        if self._value is not None:
+            return self._value
+        if isinstance(self._ticket, bytes):
+            rc, rendered, err = _ext.forward_end(self._ticket, bool(block), int(self._stream))
+        else:
+            rc = _lib.hsr_forward_end(C.byref(self._ticket), int(bool(block)), self._stream)
+            rendered, err = int(self._ticket.rendered), (_lib.hsr_last_error().decode() if rc < 0 else "")
+        if rc == HSR_PENDING:
+            return None
+        if rc == HSR_ERR_BUFFER_TOO_SMALL:
+            _binning_hint[self._key] = int(rendered)      # the next forward of this size gets room for it
+            raise RuntimeError("diff_gaussian_rasterization (async forward): " + err)
+        if rc < 0:
+            raise RuntimeError("diff_gaussian_rasterization (async forward): hsr_forward_end failed (code %d): %s" % (rc, err))
+        self._value = int(rc)
+        _binning_hint[self._key] = self._value
+        return self._value
+
+    def __int__(self):
+        return self._end(True)
+
+    __index__ = __int__
+
+    def __eq__(self, other):
+        return int(self) == other
+
+    def __ne__(self, other):
+        return int(self) != other
+
+    def __lt__(self, other):
+        return int(self) < other
+
+    def __le__(self, other):
+        return int(self) <= other
+
+    def __gt__(self, other):
+        return int(self) > other
+
+    def __ge__(self, other):
+        return int(self) >= other
+
+    def __hash__(self):
+        return hash(int(self))
+
+    def __repr__(self):
+        return "LazyRendered(%s)" % ("pending" if self._value is None else self._value)
+
+    def __format__(self, spec):
+        return format(int(self), spec)
+
+    def __add__(self, other):
+        return int(self) + other
+
+    __radd__ = __add__
+
+    def __mul__(self, other):
+        return int(self) * other
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return int(self) / other
+
+    def __floordiv__(self, other):
+        return int(self) // other
+
 
 # Gradient sink (hsr_utils/parallel.py GradientExchange): a callable (name, shape, device) -> tensor | None that may hand the
 # backward a PRE-ALLOCATED output tensor — a fresh view of a communication bucket — for a named gradient, so that the
@@ -238,12 +350,22 @@ class _Grower:
 
 def _forward_common(semantic, background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                    campos, prefiltered, debug):
+                    campos, prefiltered, debug, run_ahead=False):
+    # run ahead of the device only where it has rendered this size before (the binning buffer is sized from that count)
+    run_ahead = bool(run_ahead) and _async_forward and means3D.is_cuda and means3D.ndimension() == 2 and not debug
+    key = None
+    if run_ahead:
+        key = (means3D.device.index, int(means3D.size(0)), int(image_width), int(image_height))
+        run_ahead = key[1] > 0 and key in _binning_hint
     if _ext is not None and means3D.is_cuda:
-        return _ext.forward_common(bool(semantic), background, means3D, colors, semantics, opacity, scales, rotations,
-                                   float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
-                                   int(image_height), int(image_width), sh, int(degree), campos, bool(prefiltered), bool(debug),
-                                   torch.cuda.current_stream(means3D.device).cuda_stream)
+        stream = torch.cuda.current_stream(means3D.device).cuda_stream
+        res = _ext.forward_common(bool(semantic), background, means3D, colors, semantics, opacity, scales, rotations,
+                                  float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
+                                  int(image_height), int(image_width), sh, int(degree), campos, bool(prefiltered), bool(debug),
+                                  stream, run_ahead)
+        if res[0] == HSR_PENDING:
+            return (LazyRendered(res[10], key, stream),) + tuple(res[1:10])
+        return tuple(res[:10])
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:60-62
     _require_gpu(means3D)
@@ -273,11 +395,16 @@ def _forward_common(semantic, background, means3D, colors, semantics, opacity, s
             geom = _Grower(_lib.hsr_required_geometry_bytes(P), dev)
             img = _Grower(_lib.hsr_required_image_bytes(W, H), dev)
             hint = _binning_hint.get((dev.index, P, W, H), 4 * P)
-            binning = _Grower(_lib.hsr_required_binning_bytes(int(hint * 1.25) + 1024), dev)
+            # a call that runs ahead cannot grow the buffer afterwards: twice the last count instead of a quarter more
+            binning = _Grower(_lib.hsr_required_binning_bytes(int(hint * (2.0 if run_ahead else 1.25)) + 1024), dev)
         M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
         tens = [_prep(x, dev) for x in (background, means3D, sh, colors, semantics if semantic else None, opacity, scales,
                                         rotations, cov3D_precomp, viewmatrix, projmatrix, campos)]
         bg_, m3_, sh_, col_, sem_, op_, sc_, rot_, cov_, vm_, pm_, cp_ = tens
+        ticket = None
+        if run_ahead and P:
+            ticket = _Ticket()
+            _lib.hsr_forward_arm_async(C.byref(ticket))
         if semantic:
             rc = _lib.hsr_forward_semantic(
                 C.byref(geom.buf), C.byref(binning.buf), C.byref(img.buf), P, int(degree), M, K, _ptr(bg_), W, H, _ptr(m3_),
@@ -292,6 +419,8 @@ def _forward_common(semantic, background, means3D, colors, semantics, opacity, s
                 _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_median), _ptr(out_opacity), _ptr(out_aux), _ptr(radii),
                 int(bool(debug)), stream)
+        if rc == HSR_PENDING and ticket is not None:
+            return LazyRendered(ticket, key, stream), out_color, out_aux, out_depth, out_median, out_opacity, radii, geom.t, binning.t, img.t
         if rc < 0:
             _fail(rc, "rasterize_gaussians_semantic" if semantic else "rasterize_gaussians")
         if P:
@@ -301,23 +430,23 @@ def _forward_common(semantic, background, means3D, colors, semantics, opacity, s
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
+                        prefiltered, debug, *, run_ahead=False):
     """RasterizeGaussiansCUDA (rasterize_points.cu:36-127) ->
     (rendered, color, depth, median_depth, opacity, mask, radii, geomBuffer, binningBuffer, imgBuffer)."""
     r, color, mask, depth, median, opac, radii, g, b, i = _forward_common(
         False, background, means3D, colors, None, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-        projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug)
+        projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, run_ahead)
     return r, color, depth, median, opac, mask, radii, g, b, i
 
 
 def rasterize_gaussians_semantic(background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
-                                 degree, campos, prefiltered, debug):
+                                 degree, campos, prefiltered, debug, *, run_ahead=False):
     """RasterizeGaussiansCUDA_semantic (rasterize_points.cu:241-336) ->
     (rendered, color, semantic, depth, median_depth, opacity, radii, geomBuffer, binningBuffer, imgBuffer)."""
     r, color, sem, depth, median, opac, radii, g, b, i = _forward_common(
         True, background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-        projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug)
+        projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, run_ahead)
     return r, color, sem, depth, median, opac, radii, g, b, i
 
 
@@ -333,6 +462,7 @@ def _backward_common(semantic, background, means3D, radii, colors, semantics, sc
                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic,
                      dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
                      binningBuffer, imageBuffer, debug, want_cov3D_grad=True, geometry_only=False):
+    R = int(R)   # a LazyRendered of a forward that ran ahead resolves here (and raises if its count did not fit the binning buffer)
     sunk = None
     if _gradient_sink is not None and means3D.is_cuda and int(means3D.size(0)) != 0:
         P_, K_ = int(means3D.size(0)), (int(dL_dout_semantic.size(0)) if semantic else 0)

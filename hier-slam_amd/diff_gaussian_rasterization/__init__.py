@@ -22,7 +22,14 @@ import torch.nn as nn
 from . import _C
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "GaussianRasterizer_semantic",
-           "rasterize_gaussians", "rasterize_gaussians_semantic"]
+           "rasterize_gaussians", "rasterize_gaussians_semantic", "set_async_forward"]
+
+
+def set_async_forward(on):
+    """Opt-in: a forward that a backward will follow returns before the device has counted num_rendered (the reference — and the
+    default here — waits for that 4-byte read-back in every frame).  See diff_gaussian_rasterization/_C.py for the one condition
+    under which this raises (num_rendered more than doubling between two frames of the same size).  Returns the previous setting."""
+    return _C.set_async_forward(on)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -70,14 +77,16 @@ class _Rasterize(torch.autograd.Function):
         common = (opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
                   rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
                   rs.debug)
+        # non-blocking forward (opt-in, _C.set_async_forward): only where a backward will follow and resolve num_rendered
+        ahead = dict(run_ahead=True) if (_C._async_forward and any(ctx.needs_input_grad)) else {}
         if semantic:
             args = (rs.bg, means3D, colors_precomp, semantics_precomp) + common
             (num_rendered, color, aux, depth, median_depth, final_opacity, radii, geom, binning, img) = _call(
-                _C.rasterize_gaussians_semantic, args, rs.debug, "snapshot_fw.dump", "forward")
+                _C.rasterize_gaussians_semantic, args, rs.debug, "snapshot_fw.dump", "forward", **ahead)
         else:
             args = (rs.bg, means3D, colors_precomp) + common
             (num_rendered, color, depth, median_depth, final_opacity, aux, radii, geom, binning, img) = _call(
-                _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+                _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward", **ahead)
         ctx.semantic = semantic
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered

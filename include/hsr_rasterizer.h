@@ -110,6 +110,35 @@ int hsr_forward_semantic(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* 
                          float* out_color, float* out_semantic, float* out_depth, float* out_median_depth,
                          float* out_opacity, int* radii, int debug, void* stream);
 
+/* ---- non-blocking forward (no counterpart in the reference, whose forward stalls the stream and the host on a 4-byte
+ * cudaMemcpy of num_rendered in every frame, rasterizer_impl.cu:285 / :548) ----
+ * hsr_forward* normally returns num_rendered, i.e. waits until the device has counted the instances.  A caller that has sized the
+ * binning buffer generously (num_rendered changes slowly from frame to frame) can take the host off that wait:
+ *     hsr_ticket tk;  hsr_forward_arm_async(&tk);
+ *     rc = hsr_forward_semantic(...);           // enqueues EVERYTHING (count, emit, sort, render) and returns HSR_PENDING at once
+ *     ... enqueue more work, e.g. the loss ...
+ *     R = hsr_forward_end(&tk, 1, stream);      // num_rendered — long since written when the backward needs it
+ * If the armed call cannot run ahead (no pre-sized binning buffer, more than 8192 tiles, debug) it runs as usual and returns
+ * num_rendered; the ticket then has seq == 0.  If num_rendered turns out NOT to fit the binning buffer the device kernels that
+ * depend on it do nothing except fill the output images with NaN, hsr_forward_end returns HSR_ERR_BUFFER_TOO_SMALL (ticket->rendered
+ * holds the count) and the caller must run the forward again with a larger buffer: everything computed from those outputs in
+ * between is invalid — which is why this is opt-in and the Python layer raises (diff_gaussian_rasterization.set_async_forward). */
+#define HSR_PENDING (-100)
+typedef struct hsr_ticket {
+    uint32_t seq;                 /* 0: the armed call did not run ahead (it returned num_rendered itself) */
+    int32_t device;
+    volatile uint32_t* slot;      /* host-mapped { num_rendered, seq, prefilter flag } of this call */
+    char* binning_base;           /* the binning buffer the device kernels resolved their arrays in */
+    size_t binning_capacity;
+    int32_t prefiltered;
+    int32_t rendered;             /* out (hsr_forward_end): num_rendered, also when it did not fit */
+} hsr_ticket;
+/* arms the calling thread's NEXT hsr_forward / hsr_forward_semantic call */
+int hsr_forward_arm_async(hsr_ticket* ticket);
+/* block != 0: waits for the count (10 s watchdog, then a synchronisation of `stream`); block == 0: HSR_PENDING if it has not arrived.
+ * Returns num_rendered (>= 0), HSR_ERR_BUFFER_TOO_SMALL (outputs are NaN-filled, see above), or another negative HSR_ERR_*. */
+int hsr_forward_end(hsr_ticket* ticket, int block, void* stream);
+
 /* Replaces Rasterizer::backward (rasterizer.h:66-96, rasterizer_impl.cu:349-454).
  * R = num_rendered returned by the matching hsr_forward; the three buffers are the ones it filled.
  * dL_dmean2D is [P,3] (z unused), dL_dconic [P,4] (.z unused), dL_dopacity [P], dL_dcolor [P,3],

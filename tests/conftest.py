@@ -57,6 +57,11 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         if test_gpu_parity.TIE_BOUNDED:
             tr.write_line("comparisons that needed the oracle's tie bound (a threshold decision within ulps taken the other way): %d (%s)" % (
                 len(test_gpu_parity.TIE_BOUNDED), ", ".join(sorted(set(test_gpu_parity.TIE_BOUNDED)))))
+        if test_gpu_parity.CONDITIONED:
+            c = test_gpu_parity.CONDITIONED
+            tr.write_line("gradient comparisons settled against the TRUTH build (HIP within 2x the fp32 noise floor: oracle32 + four fp32-atomics "
+                          "orders): %d; worst element-wise HIP-vs-truth %.2e at a floor of %.2e (%s)" % (
+                              len(c), max(x[1] for x in c), max(x[2] for x in c), ", ".join(sorted(set(x[0] for x in c)))))
     except Exception:
         pass
     out_dir = os.path.join(ROOT, "gpurun_out")

@@ -43,6 +43,7 @@ CASES = {
 
 
 TIE_BOUNDED = []   # comparisons that needed the oracle's tie bound (reported at the end of the run: tests/conftest.py)
+CONDITIONED = []   # comparisons settled against the truth build: HIP within twice the fp32 noise floor of that gradient (ditto)
 
 
 def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
@@ -77,22 +78,61 @@ def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
     assert int(tie_pix.sum()) <= max(8, npix // 200), "tie-risk pixels: %d of %d" % (int(tie_pix.sum()), npix)
     assert st_o.bounds_info["overflow_pixels"] == 0, st_o.bounds_info
 
+    truth = {}   # the truth build's gradients and the fp32 noise floor per tensor, computed at most once per comparison
+
+    def conditioned(name, got, allowance):
+        """Third tier, gradients only: HIP and the fp32 oracle are two fp32 evaluations; where they differ by more than the bound the
+        TRUTH build (same lists, arithmetic in double) says who is right.  The noise floor of a gradient = how far the fp32 oracle and
+        four runs of the fp32-atomics model of the reference's own accumulation (seeded arrival orders) sit from the truth; HIP passes if
+        it is within twice that floor (+ rounding), tensor-wide and element-wise — a defect shows as HIP alone being far."""
+        import harness
+        import oracle_lib as O
+        if not truth:
+            out_t, gr_t, st_t = run_oracle(cam, sc, up, semantic=semantic, variant=variant, extra=extra, precision="f64", bounds=False)
+            st_t.free()
+            kw_ = harness.variant_kwargs(sc, variant, extra)
+            if semantic:
+                kw_["semantics_precomp"] = sc["semantics_precomp"]
+            g_ = {n: (v.numpy() if hasattr(v, "numpy") else v) for n, v in up.items()}
+            if not semantic:
+                g_["semantic"] = None
+            truth["t"] = gr_t
+            truth["m"] = [O.backward(st_o, cam, sc["means3D"], g_, median_rule="forward", fp32_atomics_seed=seed, **kw_) for seed in range(4)]
+        key = name.replace("grad ", "")
+        t = np.asarray(truth["t"][key], np.float64).reshape(np.asarray(got).shape)
+        mx = max(float(np.abs(t).max()), 1e-30)
+        fl = harness.floor_for(name)
+
+        def dist(a):
+            d = np.maximum(np.abs(np.asarray(a, np.float64).reshape(t.shape) - t) - allowance, 0.0)
+            return float(d.max() / mx), float((d / np.maximum(np.abs(t), fl * mx)).max())
+        h = dist(got)
+        floor = [max(x) for x in zip(dist(gr_o[key]), *[dist(m[key]) for m in truth["m"]])]
+        for hv, fv, what in zip(h, floor, ("tensor-wide", "element-wise")):
+            assert hv <= max(1e-4, 2.0 * fv + 2e-5), "%s: %s distance from the truth %.3e, fp32 noise floor %.3e" % (name, what, hv, fv)
+        CONDITIONED.append((name, h[1], floor[1]))
+
     def close(name, got, exp, per, **kw):
         try:
             assert_close(name, got, exp, **kw)
         except AssertionError:
             import harness
             allowance = harness.tie_allowance(name, st_o, np.asarray(got).shape, per)
-            if not (allowance > 0).any():
-                raise
-            harness.OBSERVED.pop()   # the strict attempt's record: replaced by the bounded one below
-            assert_close(name + " (beyond the oracle's tie bound)", got, exp, allowance=allowance, **kw)
-            if per == "gauss":
-                loose = harness.loosened_rows(np.asarray(exp, np.float64).reshape(np.asarray(got).shape), allowance, harness.floor_for(name))
-                rows = np.asarray(got).shape[0]
-                assert loose <= max(harness.TIE_LOOSENED_MIN, int(harness.TIE_LOOSENED_FRAC * rows)), \
-                    "%s: %d of %d rows are loosened by the tie bound" % (name, loose, rows)
-            TIE_BOUNDED.append(name)
+            try:
+                if not (allowance > 0).any():
+                    raise
+                harness.OBSERVED.pop()   # the strict attempt's record: replaced by the bounded one below
+                assert_close(name + " (beyond the oracle's tie bound)", got, exp, allowance=allowance, **kw)
+                if per == "gauss":
+                    loose = harness.loosened_rows(np.asarray(exp, np.float64).reshape(np.asarray(got).shape), allowance, harness.floor_for(name))
+                    rows = np.asarray(got).shape[0]
+                    assert loose <= max(harness.TIE_LOOSENED_MIN, int(harness.TIE_LOOSENED_FRAC * rows)), \
+                        "%s: %d of %d rows are loosened by the tie bound" % (name, loose, rows)
+                TIE_BOUNDED.append(name)
+            except AssertionError:
+                if per != "gauss" or np.asarray(got).shape[0] > 20000:    # images are never settled this way; nor full-size scenes (single-thread model)
+                    raise
+                conditioned(name, got, allowance)
 
     names = ["color", "depth", "opacity"] + (["semantic"] if semantic else ["mask"])
     for n in names:
@@ -449,3 +489,58 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_non_blocking_forward_runs_ahead_and_fails_loudly_when_the_buffer_was_too_small():
+    """diff_gaussian_rasterization.set_async_forward(True): a forward that a backward will follow returns before the device has
+    counted num_rendered (hsr_forward_arm_async); the count is a LazyRendered the backward resolves.  Same images bit for bit and
+    the same gradients as the blocking call; without gradients, and on the first call of a size, the call stays blocking; and if
+    num_rendered does not fit the binning buffer the outputs are NaN and resolving the count raises — then the next call fits."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    W, H, P, K = 203, 131, 3000, 26
+    cam, sc, up = scenes.build(W, H, P, K, seed=5, kind="slam")
+    key = (dev.index, P, W, H)
+    ref = _fwd_bwd(cam, sc, up, dev)                  # blocking; leaves the binning hint of this size
+    prev = dgr.set_async_forward(True)
+    try:
+        assert key in _C._binning_hint
+        leaf, outs = _render_sem(cam, sc, dev)
+        node = outs[0].grad_fn
+        assert isinstance(node.num_rendered, _C.LazyRendered), type(node.num_rendered)
+        upd = {n: v.to(dev) for n, v in up.items()}
+        color, radii, sem, depth, median, opac = outs
+        ((color * upd["color"]).sum() + (sem * upd["semantic"]).sum() + (depth * upd["depth"]).sum()
+         + (median * upd["median"]).sum() + (opac * upd["opacity"]).sum()).backward()
+        torch.cuda.synchronize()
+        assert int(node.num_rendered) == _C._binning_hint[key] > 0
+        for a, b in zip(ref[0], (color, sem, depth, median, opac)):
+            assert torch.equal(a, b.detach())
+        assert torch.equal(ref[1], radii)
+        for n in ref[2]:
+            assert float((ref[2][n] - leaf[n].grad).abs().max()) <= 1e-5 * max(1.0, float(ref[2][n].abs().max())), n
+        # no gradient wanted: nobody would resolve the count, so the call stays blocking
+        with torch.no_grad():
+            _, outs2 = _render_sem(cam, {n: v for n, v in sc.items()}, dev)
+        leaf3 = {n: sc[n].to(dev) for n in ("means3D", "opacities", "colors_precomp", "scales", "rotations", "semantics_precomp")}
+        from diff_gaussian_rasterization import GaussianRasterizer_semantic
+        from harness import _cam_to
+        o3 = GaussianRasterizer_semantic(_cam_to(cam, dev))(means2D=torch.zeros(P, 3, device=dev), **leaf3)
+        assert o3[0].grad_fn is None and torch.equal(o3[0], ref[0][0])
+        # overflow: a hint far too small -> the call runs ahead into a buffer that cannot hold num_rendered
+        R = _C._binning_hint[key]
+        _C._binning_hint[key] = 8
+        leaf, outs = _render_sem(cam, sc, dev)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(outs[0]).all()) and bool(torch.isnan(outs[2]).all()) and bool(torch.isnan(outs[5]).all())
+        with pytest.raises(RuntimeError, match="does not fit the binning buffer"):
+            outs[0].sum().backward()
+        assert _C._binning_hint[key] == R                                   # the count that did not fit sizes the next buffer
+        leaf, outs = _render_sem(cam, sc, dev)
+        assert isinstance(outs[0].grad_fn.num_rendered, _C.LazyRendered)
+        outs[0].sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].detach(), ref[0][0]) and int(outs[0].grad_fn.num_rendered) == R
+    finally:
+        dgr.set_async_forward(prev)

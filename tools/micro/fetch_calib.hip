@@ -26,6 +26,14 @@ __global__ void __launch_bounds__(256) stream16(const float4* __restrict__ src, 
     if (acc == 1.2345e-30f) sink[0] = acc;
 }
 
+// 4 bytes per lane, consecutive lanes consecutive words: how the tile kernels read the upstream gradient planes and write their outputs
+__global__ void __launch_bounds__(256) stream4(const float* __restrict__ src, size_t n, float* __restrict__ sink)
+{
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += src[i];
+    if (acc == 1.2345e-30f) sink[0] = acc;
+}
+
 __global__ void __launch_bounds__(256) rec_gather(const float4* __restrict__ rec, const uint32_t* __restrict__ ids, size_t n, float* __restrict__ sink)
 {
     float acc = 0.f;
@@ -76,11 +84,12 @@ int main()
     hipDeviceSynchronize();
     for (int rep = 0; rep < 3; rep++) {
         stream16<<<2048, 256>>>(rec, NREC * 4, sink);
+        stream4<<<2048, 256>>>(reinterpret_cast<const float*>(rec), NREC * 16, sink);
         rec_gather<<<2048, 256>>>(rec, ids, NREC, sink);
         row_gather<K><<<2048, 256>>>(sem, ids, NREC, sink);
     }
     hipDeviceSynchronize();
-    printf("{\"stream16_bytes\": %zu, \"rec_gather_bytes\": %zu, \"rec_gather_ids_bytes\": %zu, \"row_gather_line_bytes\": %zu, \"row_gather_row_bytes\": %zu, \"row_gather_ids_bytes\": %zu, \"launches_each\": 3}\n",
-           NREC * 64, NREC * 64, NREC * 4, row_lines * 64, NREC * (size_t)K * 4, NREC * 4);
+    printf("{\"stream4_bytes\": %zu, \"stream16_bytes\": %zu, \"rec_gather_bytes\": %zu, \"rec_gather_ids_bytes\": %zu, \"row_gather_line_bytes\": %zu, \"row_gather_row_bytes\": %zu, \"row_gather_ids_bytes\": %zu, \"launches_each\": 3}\n",
+           NREC * 64, NREC * 64, NREC * 64, NREC * 4, row_lines * 64, NREC * (size_t)K * 4, NREC * 4);
     return 0;
 }
