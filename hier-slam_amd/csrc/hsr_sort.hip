@@ -247,6 +247,73 @@ __device__ __forceinline__ void ts_block_radix(uint64_t* ka, uint32_t* va, uint6
     }
 }
 
+// ---- per-tile sort, TWO waves per tile (round 3) ----
+// At the headline workload every one of the 3 225 tiles holds 263..448 entries: tile_sort_wave_kernel gives each to ONE wave with 8
+// elements per lane, and the launch — 3.15 waves per SIMD, all resident, every wave running the same 45-step network at a third of the
+// SIMD's issue rate with a dependent LDS round trip in 21 of the steps — lasts as long as one wave does (27.8 us; waves average 19 us of
+// life, profiles/r02_h_final.json).  Two waves per tile halve the elements per lane (E = 4 for 257..512 entries: 128 lanes x 4), so every
+// step is half as long and twice as many waves hide each other's LDS round trips.  Thread = tid128 of the pair, element e = E * tid128 + r;
+// a step with stride j >= E exchanges with thread tid128 ^ (j / E): inside the wave for j / E < 64 (wave-level fence), and across the two
+// waves for exactly ONE step of the whole network (k = N, j = N / 2), bracketed by two workgroup barriers (partner's stores visible;
+// partner's loads done before the next step overwrites the slots).  Two pairs = two tiles per 256-thread workgroup; every pair
+// passes exactly those two barriers whatever its tile holds.  16 KB of exchange buffers: all 1 613 workgroups of the headline resident.  Tiles above TP_MAX entries are left to the whole workgroup afterwards (block_sort_tile), as in
+// tile_sort_wave_kernel.
+constexpr int TP_MAX = 1024;   // E = 8
+constexpr int TQ_MAX = 2048;   // four waves, E = 8: tiles of 1025..2048 entries (block_sort_tile)
+
+// NT threads (2 or 4 waves) sort N = NT * E composites held E per thread; buf: E / 2 rows of NT x 16 bytes.
+template <int E, int NT>
+__device__ __forceinline__ void net_bitonic(uint64_t (&x)[E], int tid, ulonglong2* buf)
+{
+    constexpr int N = NT * E;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    if ((r & j) == 0) {
+                        const bool up = k < E ? ((r & k) == 0) : (((E * tid) & k) == 0);
+                        const uint64_t a = x[r], b = x[r + j];
+                        const bool sw = (a > b) == up;
+                        x[r] = sw ? b : a;
+                        x[r + j] = sw ? a : b;
+                    }
+                }
+            } else {
+                const int m = j / E;                   // partner thread = tid ^ m
+                const bool cross = m >= 64;            // partner in another wave: one step of the network at two waves, three at four
+#pragma unroll
+                for (int q = 0; q < E / 2; q++) buf[q * NT + tid] = make_ulonglong2(x[2 * q], x[2 * q + 1]);
+                if (cross) {
+                    __syncthreads();
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                const bool keep_min = ((tid & m) == 0) == (((E * tid) & k) == 0);
+#pragma unroll
+                for (int q = 0; q < E / 2; q++) {
+                    const ulonglong2 y = buf[q * NT + (tid ^ m)];
+                    const uint64_t a0 = x[2 * q], a1 = x[2 * q + 1];
+                    x[2 * q] = keep_min ? (a0 < y.x ? a0 : y.x) : (a0 > y.x ? a0 : y.x);
+                    x[2 * q + 1] = keep_min ? (a1 < y.y ? a1 : y.y) : (a1 > y.y ? a1 : y.y);
+                }
+                // the next exchange's stores stay behind these loads
+                if (cross) {
+                    __syncthreads();
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+    }
+}
+
 // One tile, the whole workgroup (256 threads).  comp / hist / wcnt: the workgroup's LDS scratch.
 __device__ __forceinline__ void block_sort_tile(int tile, const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
                                                 uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
@@ -272,6 +339,28 @@ __device__ __forceinline__ void block_sort_tile(int tile, const uint2* __restric
     }
     if (n > TS_MAX) {
         ts_block_radix(keys, vals, keys_alt, vals_alt, r0, n, hist, wcnt, gid_passes);  // ends in (keys, vals)
+        return;
+    }
+    if (composite_in && n > TP_MAX) {
+        // 1025..2048 composites (every tile of the 2M-Gaussian workload at 1200x680): eight per thread in registers, the four waves
+        // exchange through LDS in 3 of the 66 steps — instead of the LDS network below (16 bytes read and written per compare-exchange,
+        // a workgroup barrier at every stride >= 128: 0.141 ms of that workload's 1.86 ms step)
+        static_assert(TQ_MAX == TS_MAX && TS_MAX * 8 >= 4 * 256 * 16, "exchange buffer = the LDS network's key array");
+        uint64_t x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int e = 8 * t + r;
+            x[r] = e < n ? keys[r0 + e] : ~0ull;
+        }
+        net_bitonic<8, 256>(x, t, reinterpret_cast<ulonglong2*>(comp));
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int e = 8 * t + r;
+            if (e < n) {
+                keys[r0 + e] = my_tile_hi | (x[r] >> 32);
+                vals[r0 + e] = (uint32_t)x[r];
+            }
+        }
         return;
     }
     int N = 64;
@@ -451,71 +540,6 @@ __global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, const uint2*
     }
 }
 
-// ---- per-tile sort, TWO waves per tile (round 3) ----
-// At the headline workload every one of the 3 225 tiles holds 263..448 entries: tile_sort_wave_kernel gives each to ONE wave with 8
-// elements per lane, and the launch — 3.15 waves per SIMD, all resident, every wave running the same 45-step network at a third of the
-// SIMD's issue rate with a dependent LDS round trip in 21 of the steps — lasts as long as one wave does (27.8 us; waves average 19 us of
-// life, profiles/r02_h_final.json).  Two waves per tile halve the elements per lane (E = 4 for 257..512 entries: 128 lanes x 4), so every
-// step is half as long and twice as many waves hide each other's LDS round trips.  Thread = tid128 of the pair, element e = E * tid128 + r;
-// a step with stride j >= E exchanges with thread tid128 ^ (j / E): inside the wave for j / E < 64 (wave-level fence), and across the two
-// waves for exactly ONE step of the whole network (k = N, j = N / 2), bracketed by two workgroup barriers (partner's stores visible;
-// partner's loads done before the next step overwrites the slots).  Two pairs = two tiles per 256-thread workgroup; every pair
-// passes exactly those two barriers whatever its tile holds.  16 KB of exchange buffers: all 1 613 workgroups of the headline resident.  Tiles above TP_MAX entries are left to the whole workgroup afterwards (block_sort_tile), as in
-// tile_sort_wave_kernel.
-constexpr int TP_MAX = 1024;   // E = 8
-
-template <int E>
-__device__ __forceinline__ void pair_bitonic(uint64_t (&x)[E], int tid, ulonglong2* buf)
-{
-    constexpr int N = 128 * E;
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j < E) {
-#pragma unroll
-                for (int r = 0; r < E; r++) {
-                    if ((r & j) == 0) {
-                        const bool up = k < E ? ((r & k) == 0) : (((E * tid) & k) == 0);
-                        const uint64_t a = x[r], b = x[r + j];
-                        const bool sw = (a > b) == up;
-                        x[r] = sw ? b : a;
-                        x[r + j] = sw ? a : b;
-                    }
-                }
-            } else {
-                const int m = j / E;                   // partner thread = tid ^ m
-                const bool cross = m >= 64;            // the one step that pairs the two waves
-#pragma unroll
-                for (int q = 0; q < E / 2; q++) buf[q * 128 + tid] = make_ulonglong2(x[2 * q], x[2 * q + 1]);
-                if (cross) {
-                    __syncthreads();
-                } else {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-                const bool keep_min = ((tid & m) == 0) == (((E * tid) & k) == 0);
-#pragma unroll
-                for (int q = 0; q < E / 2; q++) {
-                    const ulonglong2 y = buf[q * 128 + (tid ^ m)];
-                    const uint64_t a0 = x[2 * q], a1 = x[2 * q + 1];
-                    x[2 * q] = keep_min ? (a0 < y.x ? a0 : y.x) : (a0 > y.x ? a0 : y.x);
-                    x[2 * q + 1] = keep_min ? (a1 < y.y ? a1 : y.y) : (a1 > y.y ? a1 : y.y);
-                }
-                // the next exchange's stores stay behind these loads
-                if (cross) {
-                    __syncthreads();
-                } else {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-            }
-        }
-    }
-}
-
 template <int E>
 __device__ __forceinline__ void pair_sort_tile(int r0, int n, int tid, uint64_t tile_hi, uint64_t* __restrict__ keys,
                                                uint32_t* __restrict__ vals, ulonglong2* buf)
@@ -526,7 +550,7 @@ __device__ __forceinline__ void pair_sort_tile(int r0, int n, int tid, uint64_t 
         const int e = E * tid + r;
         x[r] = e < n ? keys[r0 + e] : ~0ull;
     }
-    pair_bitonic<E>(x, tid, buf);
+    net_bitonic<E, 128>(x, tid, buf);
 #pragma unroll
     for (int r = 0; r < E; r++) {
         const int e = E * tid + r;
@@ -537,7 +561,7 @@ __device__ __forceinline__ void pair_sort_tile(int r0, int n, int tid, uint64_t 
     }
 }
 
-__global__ void __launch_bounds__(256) tile_sort_pair_kernel(int T, const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+__global__ void __launch_bounds__(256, 7) tile_sort_pair_kernel(int T, const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
                                                              uint32_t* __restrict__ vals, uint64_t* __restrict__ keys_alt,
                                                              uint32_t* __restrict__ vals_alt, int gid_passes, int big_too, BinDevRef ref)
 {

@@ -237,7 +237,13 @@ static long g_median_disagree = 0;
  * ill-conditioned gradient from a defect). */
 static int g_accum_fp32 = 0;
 static unsigned g_accum_seed = 0;
+/* In the fp32 model the exponential may also carry the error a GPU's own exp has: G is multiplied by 1 + u * ulps * 2^-23 with u
+ * uniform in [-1, 1], hashed from (seed, pixel, list position).  glibc's expf is within ~0.5 ulp; CUDA documents 2 ulp for expf (the
+ * reference is built without fast-math: setup.py has no such flag), gfx950's v_exp_f32 / v_rcp_f32 1 ulp each.  Decisions (alpha >= 1/255
+ * ...) keep using the unperturbed value: the model varies the arithmetic, not the lists. */
+static float g_exp_ulps = 0.0f;
 void hsro_set_accumulation(int fp32, unsigned seed) { g_accum_fp32 = fp32 ? 1 : 0; g_accum_seed = seed; }
+void hsro_set_exp_error(float ulps) { g_exp_ulps = ulps > 0 ? ulps : 0.0f; }
 void hsro_set_median_rule(int rule) { g_median_rule = rule ? 1 : 0; }
 long hsro_last_median_rule_disagreements(void) { return g_median_disagree; }
 
@@ -737,11 +743,18 @@ static int pixel_backward(const HsroBwdCtx* c, size_t pix_id, float pfx, float p
         int skip = power > 0.0f;
         if (ovr.kind == 1 && ovr.pos == ii - 1) skip = !skip;
         if (skip) continue;
-        const real G = R_EXP(power);
-        const real alpha = fmin_r(0.99f, co[3] * G);
+        real G = R_EXP(power);
+        real alpha = fmin_r(0.99f, co[3] * G);
         skip = alpha < 1.0f / 255.0f;
         if (ovr.kind == 2 && ovr.pos == ii - 1) skip = !skip;
         if (skip) continue;
+        if (acc32 && g_exp_ulps > 0.0f) {   /* fp32 model: an exp that is off by up to g_exp_ulps ulps (hsro_set_exp_error) */
+            uint64_t hsh = ((uint64_t)pix_id * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)ii * 0xC2B2AE3D27D4EB4Full) ^ ((uint64_t)g_accum_seed << 32);
+            hsh ^= hsh >> 29; hsh *= 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 32;
+            const float u = (float)((double)(hsh & 0xFFFFFFu) / 8388607.5 - 1.0);
+            G = G * (1.0f + u * g_exp_ulps * 1.1920929e-7f);
+            alpha = fmin_r(0.99f, co[3] * G);
+        }
         real test_T = T / (1.f - alpha);
         const real w = alpha * test_T;
         double* a = local ? local + (size_t)(ii - 1 - r0) * NA : acc + (size_t)id * NA;

@@ -168,7 +168,7 @@ def forward(cam, means3D, opacities, colors_precomp=None, shs=None, semantics_pr
 
 
 def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_precomp=None, scales=None,
-             rotations=None, cov3D_precomp=None, threads=0, median_rule="reference", bounds=False, fp32_atomics_seed=None):
+             rotations=None, cov3D_precomp=None, threads=0, median_rule="reference", bounds=False, fp32_atomics_seed=None, exp_ulps=0.0):
     """Oracle backward.  grads: dict(color[3,H,W], semantic[K,H,W]|None, depth, median, opacity).
     median_rule: "reference" = the splat the backward re-finds from its reconstructed T (backward.cu:623-626, :854-857);
     "forward" = the splat whose list position the forward recorded (what the HIP product does; identical except where the
@@ -180,7 +180,10 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
     rt = L.real
     # fp32_atomics_seed: the per-Gaussian sums are accumulated in fp32 in a seeded random tile order — one of the orders the reference's
     # (or the HIP kernels') fp32 atomicAdds can arrive in — instead of in double (oracle/hsr_oracle.c hsro_set_accumulation)
+    # exp_ulps (fp32 model only): the exponential of every (pixel, splat) pair is off by up to that many ulps, hashed from the seed —
+    # a GPU's exp (v_exp_f32: 1 ulp; CUDA's expf: 2 ulp documented) instead of glibc's
     L.hsro_set_accumulation(C.c_int(0 if fp32_atomics_seed is None else 1), C.c_uint(int(fp32_atomics_seed or 0)))
+    L.hsro_set_exp_error(C.c_float(float(exp_ulps) if fp32_atomics_seed is not None else 0.0))
     L.hsro_set_median_rule(C.c_int({"reference": 0, "forward": 1}[median_rule]))
     if threads:
         L.hsro_set_threads(C.c_int(threads))
@@ -230,6 +233,7 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
     o["median_rule_disagreements"] = int(L.hsro_last_median_rule_disagreements())
     L.hsro_set_median_rule(C.c_int(0))
     L.hsro_set_accumulation(C.c_int(0), C.c_uint(0))
+    L.hsro_set_exp_error(C.c_float(0.0))
     return o
 
 

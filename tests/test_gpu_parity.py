@@ -97,7 +97,7 @@ def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
             if not semantic:
                 g_["semantic"] = None
             truth["t"] = gr_t
-            truth["m"] = [O.backward(st_o, cam, sc["means3D"], g_, median_rule="forward", fp32_atomics_seed=seed, **kw_) for seed in range(4)]
+            truth["m"] = [O.backward(st_o, cam, sc["means3D"], g_, median_rule="forward", fp32_atomics_seed=seed, exp_ulps=harness.FP32_MODEL_EXP_ULPS, **kw_) for seed in range(4)]
         key = name.replace("grad ", "")
         t = np.asarray(truth["t"][key], np.float64).reshape(np.asarray(got).shape)
         mx = max(float(np.abs(t).max()), 1e-30)
