@@ -363,6 +363,12 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_bl
     for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cnt[i] = 0u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g0 = blockIdx.x * per_block;   // per_block is a multiple of 1024: chunks coincide with 4 preprocess blocks
+    // first chunk's Gaussians requested before the prefix over the block sums, every later chunk one iteration ahead (see bin_emit_kernel)
+    uint32_t n_touched; int n_radius; float2 n_xy;
+    {
+        const int i0 = min(g0 + (int)threadIdx.x, P - 1);
+        n_touched = g.tiles_touched[i0]; n_radius = radii[i0]; n_xy = g.means2D[i0];
+    }
     // The scan over the preprocess blocks' tile-count sums rides along here (no separate single-workgroup launch): this
     // workgroup sums the RAW per-block sums in front of its first Gaussian itself — at most P/256 L2-resident words — and the
     // last workgroup, whose running sum ends at the total, publishes num_rendered.
@@ -378,7 +384,13 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_bl
     for (int k = 0; k < BIN_THREADS / 64; k++) chunk_base += s_red[k];
     for (int c = 0; c < per_block && g0 + c < P; c += BIN_THREADS) {
         const int idx = g0 + c + threadIdx.x;
-        const uint32_t touched = idx < P ? g.tiles_touched[idx] : 0u;
+        const uint32_t touched = idx < P ? n_touched : 0u;
+        const int radius_cur = n_radius;
+        const float2 xy_cur = n_xy;
+        {
+            const int in = min(idx + BIN_THREADS, P - 1);
+            n_touched = g.tiles_touched[in]; n_radius = radii[in]; n_xy = g.means2D[in];
+        }
         // inclusive scan inside the wave, then the sums of the earlier waves of the same 256-Gaussian preprocess block
         uint32_t inc = touched;
 #pragma unroll
@@ -403,9 +415,9 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_hist_kernel(int P, int per_bl
         for (int k = w & ~3; k < w; k++) off += s_wsum[k];
         if (idx < P) {
             g.point_offsets[idx] = off + inc;
-            const int radius = radii[idx];
+            const int radius = radius_cur;
             if (radius > 0) {
-                const float2 xy = g.means2D[idx];
+                const float2 xy = xy_cur;
                 uint32_t x0, y0, x1, y1;
                 tile_rect(xy.x, xy.y, radius, tiles_x, tiles_y, x0, y0, x1, y1);
                 for (uint32_t y = y0; y < y1; y++)
@@ -467,6 +479,16 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_emit_kernel(int P, int per_bl
     __shared__ uint32_t s_scan[BIN_THREADS / 64 + 1];
     const int T = tiles_x * tiles_y;
     const uint32_t* row = table + (size_t)blockIdx.x * T;
+    // The Gaussians of this workgroup's first chunk are requested NOW, before the scan of the tile totals below (three workgroup
+    // barriers and two rounds of L2 loads that these loads do not depend on), and every later chunk one iteration ahead: the kernel is
+    // a chain of dependent round trips (67 % of its wave cycles were waits), not bandwidth.  Unconditional, clamped loads.
+    const int g0 = blockIdx.x * per_block;
+    const int g1 = min(P, g0 + per_block);
+    int n_radius; float2 n_xy; float n_depth;
+    {
+        const int i0 = min(g0 + (int)threadIdx.x, P - 1);
+        n_radius = radii[i0]; n_xy = g.means2D[i0]; n_depth = g.depths[i0];
+    }
     // segment starts = exclusive scan of the tile totals: every workgroup scans the (L2-resident) totals itself — T <= 8192 words,
     // at most 8 per thread — instead of reading them from a single-workgroup launch of their own; workgroup 0 also writes the
     // reference's tile ranges (identifyTileRanges, rasterizer_impl.cu:116-138; untouched tiles keep {0,0} as after its memset, :314)
@@ -493,17 +515,21 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_emit_kernel(int P, int per_bl
         }
     }
     __syncthreads();
-    const int g0 = blockIdx.x * per_block;
-    const int g1 = min(P, g0 + per_block);
-    for (int idx = g0 + threadIdx.x; idx < g1; idx += BIN_THREADS) {
-        const int radius = radii[idx];
-        if (radius <= 0) continue;
-        const float2 xy = g.means2D[idx];
+    for (int base = g0; base < g1; base += BIN_THREADS) {
+        const int idx = base + threadIdx.x;
+        const int radius = n_radius;
+        const float2 xy = n_xy;
+        const float depth = n_depth;
+        {
+            const int in = min(idx + BIN_THREADS, P - 1);
+            n_radius = radii[in]; n_xy = g.means2D[in]; n_depth = g.depths[in];
+        }
+        if (idx >= g1 || radius <= 0) continue;
         uint32_t x0, y0, x1, y1;
         tile_rect(xy.x, xy.y, radius, tiles_x, tiles_y, x0, y0, x1, y1);
         // the tile is implied by the segment: one 8-byte store of the sort composite (depth bits, index) per instance;
         // tile_sort_kernel turns it into the reference's (tile | depth) key and the index value
-        const uint64_t c = ((uint64_t)__float_as_uint(g.depths[idx]) << 32) | (uint64_t)(uint32_t)idx;
+        const uint64_t c = ((uint64_t)__float_as_uint(depth) << 32) | (uint64_t)(uint32_t)idx;
         for (uint32_t y = y0; y < y1; y++)
             for (uint32_t x = x0; x < x1; x++) comp[atomicAdd(&s_cur[y * (uint32_t)tiles_x + x], 1u)] = c;
     }
