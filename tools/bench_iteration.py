@@ -19,6 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hier-slam_amd"))
 
 
+REPEATS = 3
+
+
 def measure(P=500000, W=1200, H=680, iters=20):
     from diff_gaussian_rasterization import GaussianRasterizer_semantic
     from hsr_utils import slam_helpers as SH, losses as L, setup_camera, make_scene
@@ -91,14 +94,17 @@ def measure(P=500000, W=1200, H=680, iters=20):
     def timeit(fused, leaf=False):
         for _ in range(3):
             iteration(fused, leaf)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            for v in list(params.values()) + list(mlp.parameters()):
-                v.grad = None
-            iteration(fused, leaf)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters * 1e3
+        best = float("inf")
+        for _ in range(REPEATS):   # host-side times: the fastest of a few repeats (a box's other tenants show up as +10-20 %)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                for v in list(params.values()) + list(mlp.parameters()):
+                    v.grad = None
+                iteration(fused, leaf)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / iters * 1e3)
+        return best
     def tracking(fused, pose_only=False):
         """scripts/hierslam.py:1683-1860 per iteration: pose gradients only, masked L1 sums on depth and colour.  pose_only: the map
         tensors are detached (the reference leaves them attached with learning rate 0, so their gradients are computed and thrown
@@ -118,15 +124,26 @@ def measure(P=500000, W=1200, H=680, iters=20):
     def time_tracking(fused, pose_only=False):
         for _ in range(3):
             tracking(fused, pose_only)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            for v in params.values():
-                v.grad = None
-            tracking(fused, pose_only)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters * 1e3
+        best = float("inf")
+        for _ in range(REPEATS):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                for v in params.values():
+                    v.grad = None
+                tracking(fused, pose_only)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / iters * 1e3)
+        return best
     lf, le = float(iteration(True).detach()), float(iteration(False).detach())
+    # the opt-in non-blocking forward (diff_gaussian_rasterization.set_async_forward): the host no longer waits for num_rendered in
+    # every frame, so the Python side of the iteration overlaps the device side of the previous one
+    from diff_gaussian_rasterization import set_async_forward
+    was = set_async_forward(True)
+    run_ahead = {"note": "same fused iterations with set_async_forward(True)", "fused_ms": timeit(True), "tracking_fused_ms": time_tracking(True),
+                 "tracking_fused_map_detached_ms": time_tracking(True, True), "with_leaf_head_fused_ms": timeit(True, True),
+                 "loss_fused": float(iteration(True).detach())}
+    set_async_forward(was)
     return {"workload": "mapping iteration without optimizer: prep + semantic render + mapping losses + backward, %dx%d, P=%d, K=%d" % (W, H, P, K),
             "fused_ms": timeit(True), "eager_around_same_rasterizer_ms": timeit(False), "loss_fused": lf, "loss_eager": le,
             "tracking_iteration": {"note": "pose-only iteration (scripts/hierslam.py:1683-1860): prep with camera_grad, render, masked L1 sums, backward",
@@ -135,7 +152,8 @@ def measure(P=500000, W=1200, H=680, iters=20):
                                    "note2": "map tensors detached -> geometry-only rasterizer backward (one 64-byte row per Gaussian, no semantic upstream gradients)"},
             "with_leaf_head": {"note": "mapping iterations >= 14 add the 1x1-conv leaf MLP + cross-entropy (scripts/hierslam.py:975-983)",
                                "fused_ms": timeit(True, True), "eager_around_same_rasterizer_ms": timeit(False, True),
-                               "loss_fused": float(iteration(True, True).detach()), "loss_eager": float(iteration(False, True).detach())}}
+                               "loss_fused": float(iteration(True, True).detach()), "loss_eager": float(iteration(False, True).detach())},
+            "non_blocking_forward": run_ahead}
 
 
 if __name__ == "__main__":
