@@ -177,8 +177,7 @@ struct RenderFwdArgs {
     BinDevRef bin;    // base != NULL: point_list is resolved on the device (speculative forward)
 };
 int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream);
-bool hsr_launch_render_forward_pair(const RenderFwdArgs& a, hipStream_t stream);  // non-semantic / K <= 27, pair-pipelined MFMA
-bool hsr_launch_render_forward_wide(const RenderFwdArgs& a, hipStream_t stream);  // semantic, 29 <= K <= 124; false otherwise
+bool hsr_launch_render_forward_wide(const RenderFwdArgs& a, hipStream_t stream);  // experiments/ (ablate build): semantic, 29 <= K <= 124; false otherwise
 
 struct RenderBwdArgs {
     int W, H, K, semantic, P;

@@ -266,37 +266,25 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
     const dim3 grid(hsr_tile_grid(tiles)), block(256);
-    // default for K <= 27: the matrix-core kernel (hsr_render_bwd_mfma.hip), half the VALU instructions of the
-    // all-VALU kernels below, which serve K > 27 and HSR_BWD_IMPL=valu (A/B timing, tests).
-    // the matrix-core kernels address the packed rows with 32-bit element indices: beyond 2^30 row elements (P > 22 M Gaussians
-    // at K = 26) the all-VALU kernels below, which use 64-bit addressing, take over
+    // Default (packed accumulation rows, a.grow): the matrix-core kernels on 4x4 sub-block lists (hsr_render_bwd_sub.hip) — `sub` for
+    // K <= 27, one-pass `subw` beyond.  They address the packed rows with 32-bit element indices; beyond 2^30 row elements (P > 22 M
+    // Gaussians at K = 26), in the legacy accumulation mode (no scratch: atomics straight into the six output arrays, like the
+    // reference) and under HSR_BWD_IMPL=valu (A/B timing, tests) the all-VALU kernel of this file takes over: 64-bit addressing, any K.
+    // Round 1's quadrant-list matrix-core kernels live in experiments/ (HSR_BWD_IMPL=mfma in the ablate build).
     const bool rows_fit_32bit = !a.grow || (size_t)a.P * (size_t)a.grow_stride < ((size_t)1 << 30);
-    static const bool env_mfma = !(getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "valu"));
-    const bool use_mfma = env_mfma && rows_fit_32bit;
-    if (use_mfma && (a.semantic ? a.K : 0) <= 27) {  // one matrix-core launch covers the base sums + K <= 27 channels
-        // default: 16-lane groups on 4x4 sub-block masks (hsr_render_bwd_sub.hip, packed rows only), 0.37 ms at the headline
-        // workload; HSR_BWD_IMPL=mfma: all 64 lanes on the quadrant list (hsr_render_bwd_mfma.hip, 0.42 ms; also serves the
-        // legacy accumulation mode); HSR_BWD_IMPL=mom (ablate build only): the moments experiment
-        static const char* impl = getenv("HSR_BWD_IMPL");
-        static const bool use_quad = impl && !strcmp(impl, "mfma");
+    static const char* impl = getenv("HSR_BWD_IMPL");
+    static const bool force_valu = impl && !strcmp(impl, "valu");
+    const int Ksem = a.semantic ? a.K : 0;
 #ifdef HSR_ABLATE
-        static const bool use_mom = impl && !strcmp(impl, "mom");
-        if (use_mom && a.grow) {
-            hsr_launch_render_backward_mom(a, stream);
-            return HSR_OK;
-        }
+    static const bool use_quad = impl && !strcmp(impl, "mfma");
+    static const bool use_mom = impl && !strcmp(impl, "mom");
+    if (!force_valu && rows_fit_32bit) {
+        if (use_mom && a.grow && Ksem <= 27) return hsr_launch_render_backward_mom(a, stream);
+        if (use_quad) return Ksem <= 27 ? hsr_launch_render_backward_mfma(a, stream) : hsr_launch_render_backward_wide(a, stream);
+    }
 #endif
-        if (!use_quad && a.grow) hsr_launch_render_backward_sub(a, stream);
-        else hsr_launch_render_backward_mfma(a, stream);
-        return HSR_OK;
-    }
-    if (use_mfma && a.semantic && a.K > 27) {  // wide trees: matrix-core passes of <= 64 channels
-        // default: sub-block masks (hsr_render_bwd_sub.hip, packed rows); HSR_BWD_IMPL=mfma: quadrant lists (hsr_render_bwd_wide.hip)
-        static const bool use_quad_w = getenv("HSR_BWD_IMPL") && !strcmp(getenv("HSR_BWD_IMPL"), "mfma");
-        if (a.grow && !use_quad_w) hsr_launch_render_backward_subw(a, stream);
-        else hsr_launch_render_backward_wide(a, stream);
-        return HSR_OK;
-    }
+    if (!force_valu && rows_fit_32bit && a.grow)
+        return Ksem <= 27 ? hsr_launch_render_backward_sub(a, stream) : hsr_launch_render_backward_subw(a, stream);
     if (!a.semantic || a.K == 0) {
         render_bwd_kernel<0, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;

@@ -1,7 +1,7 @@
 // hsr_render_bwd_sub.hip — backward tile kernel whose 16-lane groups walk 4x4 SUB-BLOCK lists (packed mode, K <= 27).
 //
 // Same per-pixel semantics as hsr_render_bwd.hip (reference backward.cu:472-899, see that file's header) and the same
-// matrix-core contraction for the K+5 "direct" sums as hsr_render_bwd_mfma.hip.  What changes is WHO visits a splat.
+// matrix-core contraction for the K+5 "direct" sums as experiments/hsr_render_bwd_mfma.hip (round 1).  What changes is WHO visits a splat.
 // In the quadrant kernels a wave walks one list and all 64 lanes evaluate every entry, but a SLAM-sized splat reaches
 // alpha >= 1/255 on ~40 pixels: 15-20 % of the lanes of its ~3 quadrant visits do useful work.  Here every 16-lane group
 // of a wave owns one 4x4 sub-block (hsr_tile_common.h, tile_geom_sub) and only visits the splats whose alpha bounding box
@@ -18,7 +18,7 @@
 //   * the 7 values that are not of the form sum_pixels w*g are reduced over the 16 lanes of the group (four in-row
 //     butterfly stages) into a per-(entry, group) slot and summed over the groups once per chunk;
 //   * the chunk's rows leave with one atomic per accumulator register (4 rows x 64 bytes each) plus two for the butterfly
-//     columns (8 rows x 7 values each): the same 3 requests per (splat, quadrant) as hsr_render_bwd_mfma.hip.
+//     columns (8 rows x 7 values each): the same 3 requests per (splat, quadrant) as experiments/hsr_render_bwd_mfma.hip (round 1).
 // Merging further, over the TILE, would cut the atomic requests by a quarter — they execute at the memory side at a
 // fixed rate (MI355X guide, "Global float atomics"; twice the requests = +0.15 ms here) — but the only place the four
 // waves can meet is an LDS table, and ds_add_f32 costs ~170 cycles per wave-instruction on gfx950 (measured with exactly
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_sub_kernel(RenderBwdArgs a)
     const long long tr_t0 = TR_NOW();
     (void)tr_stage; (void)tr_loop; (void)tr_flush; (void)tr_iters; (void)tr_chunks; (void)tr_accepted; (void)tr_t0;
 
-    // every prologue load unconditional and issued before anything consumes one (see hsr_render_bwd_mfma.hip)
+    // every prologue load unconditional and issued before anything consumes one (see experiments/hsr_render_bwd_mfma.hip)
     const size_t pix_ld = inside ? pix_id : 0;
     const float inm = inside ? 1.f : 0.f;
     const float T_final_ld = a.final_T[pix_ld];
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
     const uint2 range = a.ranges[tile];
     float* u7 = s_u7[wv];
 
-    // every prologue load unconditional and issued before anything consumes one (see hsr_render_bwd_mfma.hip)
+    // every prologue load unconditional and issued before anything consumes one (see experiments/hsr_render_bwd_mfma.hip)
     const size_t pix_ld = inside ? pix_id : 0;
     const float inm = inside ? 1.f : 0.f;
     const float T_final_ld = a.final_T[pix_ld];
@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_geo_kernel(RenderBwdArgs a)
     }
 }
 
-// Wide trees (K > 27), in channel passes like hsr_render_bwd_wide.hip: semantic channels [c0, c0 + ns) of the image; the BASE
+// Wide trees (K > 27), in channel passes like experiments/hsr_render_bwd_wide.hip: semantic channels [c0, c0 + ns) of the image; the BASE
 // pass adds the five direct sums and the seven butterfly values, a SEM pass only re-derives alpha and T and feeds the panel.
 // 16 * NG >= ns + (BASE ? 5 : 0).
 // BF: the panel contraction runs on the bf16 matrix cores (split3_bf16): 24 registers of B operand per 16 columns instead of 16.
@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(256, BF ? 2 : (NG <= 2 ? 4 : (NG <= 4 ? 3 : 2)
     float* panel = s_panel[wv];
     float* u7 = s_u7[wv];
 
-    // every prologue load unconditional and issued before anything consumes one (see hsr_render_bwd_mfma.hip)
+    // every prologue load unconditional and issued before anything consumes one (see experiments/hsr_render_bwd_mfma.hip)
     const size_t pix_ld = inside ? pix_id : 0;
     const float inm = inside ? 1.f : 0.f;
     const float T_final_ld = a.final_T[pix_ld];

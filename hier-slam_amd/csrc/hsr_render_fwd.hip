@@ -611,37 +611,28 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     const dim3 grid(hsr_tile_grid(tiles)), block(256);
     // Default for K <= 28: the per-lane kernel on 4x4 sub-block lists (SUB).  Measured at the headline workload (500k
     // Gaussians, 1200x680, K = 26): 0.18 ms against 0.22 ms for the same kernel on quadrant lists (HSR_FWD_IMPL=valu, kept
-    // for A/B timing and tests) and 0.27 ms for the pair-pipelined matrix-core kernel (HSR_FWD_IMPL=mfma in the ablate build,
-    // experiments/hsr_render_fwd_pair.hip: the ~25 VALU instructions that evaluate alpha per list entry dominate, the matrix cores
-    // only take the 15 packed FMAs behind them, and every list entry has to go through the pair).
+    // for A/B timing and tests) and 0.27 ms for round 1's pair-pipelined matrix-core kernel (EXPERIMENTS.md §4: the ~25 VALU
+    // instructions that evaluate alpha per list entry dominate, the matrix cores only take the 15 packed FMAs behind them, and every list
+    // entry has to go through the pair; removed in round 3 — it predates the saved sub-block masks and median positions the backward reads).
     static const char* impl = getenv("HSR_FWD_IMPL");
     static const bool force_valu = impl && !strcmp(impl, "valu");   // quadrant lists, per-lane accumulators for every K
-#ifdef HSR_ABLATE
-    static const bool use_pair = impl && !strcmp(impl, "mfma");
-    if (use_pair && hsr_launch_render_forward_pair(a, stream)) return HSR_OK;
-#endif
     if (!a.semantic) {
         if (force_valu) render_fwd_kernel<0, true, true, false, false><<<grid, block, 0, stream>>>(a, 0);
         else render_fwd_kernel<0, true, true, false, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;
     }
-    // wide trees (29 <= K <= 124): matrix-core accumulation (hsr_render_fwd_wide.hip) unless HSR_FWD_IMPL=valu asks for
-    // the per-lane accumulators below.  Measured at 500k Gaussians, 1200x680 (tools/kcompare.sh), wide vs per-lane:
-    // K=33 0.41/0.59 ms, 60 0.43/0.62, 90 0.62/0.96, 102 0.70/1.16, 124 0.71/1.24 — and K=74 0.61/0.54, the one
-    // width whose fused per-lane instantiation (222 registers, 2 waves/SIMD) still wins, so it keeps it (0.47 ms on
-    // sub-block lists).
-    // Round 2: with the rows of the next batch touched into L2 instead of parked in registers (PF), the per-lane kernel on
-    // sub-block lists runs at three or four waves per SIMD up to 80 channels and beats the matrix-core kernel there (500k
-    // Gaussians: K = 32 0.41 -> see profiles/r02_fwd_generic_k.log); the matrix-core kernel keeps 81 <= K <= 124.
-    // HSR_FWD_IMPL=wide restores its old range (parity-tested).
-    static const bool prefer_wide = impl && !strcmp(impl, "wide");
-    // Late round 2: with quad-shared rows the per-lane kernel also wins beyond 80 channels (tools/fwd_pf_max.sh, 500k Gaussians: K = 90
-    // 0.644 -> 0.557 ms, K = 102 0.712 -> 0.617, K = 124 0.732 -> 0.695) at two waves per SIMD: it takes every K in 27..128 now and the
-    // matrix-core forward is what HSR_FWD_IMPL=wide selects.
+    // Wide trees.  Round 1 accumulated 29 <= K <= 124 on the matrix cores (experiments/hsr_render_fwd_wide.hip; HSR_FWD_IMPL=wide in the
+    // ablate build still selects it).  Since round 2 the per-lane kernel on sub-block lists takes every K: with the rows of the next batch
+    // touched into L2 instead of parked in registers (PF) it runs at three or four waves per SIMD up to 80 channels, and with quad-shared
+    // rows it also wins beyond (tools/fwd_pf_max.sh, 500k Gaussians, matrix-core -> per-lane: K = 90 0.644 -> 0.557 ms, K = 102
+    // 0.712 -> 0.617, K = 124 0.732 -> 0.695; profiles/r02_fwd_generic_k.log for the narrower ones).
     // (K = 74 and K = 102 — the reference's large ScanNet tree and its flat Replica label set — have instantiations of their exact width
     // below: rows fetched as aligned float2, no padding channels: K = 74 0.371 vs 0.430 ms through the 80-channel kernel)
-    const bool per_lane_pf = !force_valu && !prefer_wide && a.K >= 27 && a.K <= 128 && a.K != 74 && a.K != 102;
-    if (per_lane_pf) {
+#ifdef HSR_ABLATE
+    static const bool prefer_wide = impl && !strcmp(impl, "wide");
+    if (prefer_wide && hsr_launch_render_forward_wide(a, stream)) return HSR_OK;
+#endif
+    if (!force_valu && a.K >= 27 && a.K <= 128 && a.K != 74 && a.K != 102) {
         if (a.K <= 32) render_fwd_kernel<32, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
         else if (a.K <= 48) render_fwd_kernel<48, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
         else if (a.K <= 64) render_fwd_kernel<64, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
@@ -651,7 +642,6 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
         else render_fwd_kernel<128, true, false, false, true, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;
     }
-    if (!force_valu && a.K != 74 && (a.K != 102 || prefer_wide) && hsr_launch_render_forward_wide(a, stream)) return HSR_OK;
     if (!force_valu) {
         switch (a.K) {
         case 0: render_fwd_kernel<0, true, false, false, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;
@@ -664,20 +654,15 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
             return HSR_OK;
         }
         case 102:   // Replica flat label set
-            if (!prefer_wide) {
-                render_fwd_kernel<102, true, false, true, true, true><<<grid, block, 0, stream>>>(a, 0);
-                return HSR_OK;
-            }
-            break;
-        default:
-            if (a.K > 124 || a.K <= 28) {   // 32-channel chunks; the first chunk also produces the base outputs
-                render_fwd_kernel<32, true, false, false, true><<<grid, block, 0, stream>>>(a, 0);
-                for (int c0 = 32; c0 < a.K; c0 += 32) render_fwd_kernel<32, false, false, false, true><<<grid, block, 0, stream>>>(a, c0);
-                return HSR_OK;
-            }
-            break;
+            render_fwd_kernel<102, true, false, true, true, true><<<grid, block, 0, stream>>>(a, 0);
+            return HSR_OK;
+        default:   // K <= 26 or K > 128: 32-channel chunks; the first chunk also produces the base outputs
+            render_fwd_kernel<32, true, false, false, true><<<grid, block, 0, stream>>>(a, 0);
+            for (int c0 = 32; c0 < a.K; c0 += 32) render_fwd_kernel<32, false, false, false, true><<<grid, block, 0, stream>>>(a, c0);
+            return HSR_OK;
         }
     }
+    // HSR_FWD_IMPL=valu: quadrant lists, per-lane accumulators
     switch (a.K) {
     case 0: render_fwd_kernel<0, true, false, false><<<grid, block, 0, stream>>>(a, 0); break;
     case 16: render_fwd_kernel<16, true, false, true><<<grid, block, 0, stream>>>(a, 0); break;   // ScanNet tree

@@ -140,7 +140,7 @@ def test_forward_is_deterministic_and_backward_reproducible_within_fp32_noise():
 
 
 def test_experimental_modes_are_not_in_the_product_library():
-    """the per-instance rows accumulation (and the moments / pair-pipelined kernels) were measured slower and live in the
+    """the per-instance rows accumulation (and the moments kernels) were measured slower and live in the
     ablate build only (csrc/experiments/, `make -C hier-slam_amd/csrc ablate`): the product refuses the mode"""
     from diff_gaussian_rasterization import _C
     with pytest.raises(RuntimeError, match="ablate build"):
@@ -164,12 +164,23 @@ def test_parity_other_accumulation_modes(name, mode):
         _C.set_backward_mode("packed")
 
 
+ABLATE_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hier-slam_amd", "libhsr_rast_ablate.so")
+
+
+def _ablate_env(**extra):
+    """environment of a child process that runs the diagnostic library (`make -C hier-slam_amd/csrc ablate`: csrc/experiments/ linked
+    in, ablation switches live) through the ctypes glue; skips the test when that library was not built"""
+    if not os.path.exists(ABLATE_LIB):
+        pytest.skip("libhsr_rast_ablate.so not built (make -C hier-slam_amd/csrc ablate): experimental kernel families are not in the product")
+    return dict(os.environ, HSR_RAST_LIB=ABLATE_LIB, HSR_GLUE="ctypes", **extra)
+
+
 @pytest.mark.parametrize("impl", ["mfma", "valu"])
 def test_parity_alternate_kernels(impl):
-    """kernel families are selected per process (HSR_FWD_IMPL / HSR_BWD_IMPL; defaults for K <= 27: per-lane forward and
-    matrix-core backward on 4x4 sub-block lists).  "mfma" = the quadrant-list matrix-core backward (the fallback of the legacy
-    accumulation mode), "valu" = quadrant-list per-lane kernels both ways (the fallback beyond 2^30 row elements): every family
-    the product library can reach runs the parity cases, each in a child process"""
+    """kernel families are selected per process (HSR_FWD_IMPL / HSR_BWD_IMPL; defaults: per-lane forward and matrix-core backward
+    on 4x4 sub-block lists).  "valu" = quadrant-list per-lane kernels both ways — the product's fallback for the legacy accumulation
+    mode and beyond 2^30 row elements; "mfma" = round 1's quadrant-list matrix-core backward, since round 3 in the ablate build only
+    (csrc/experiments/).  Parity cases, each family in a child process"""
     import subprocess
     import sys
     code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
@@ -177,7 +188,7 @@ def test_parity_alternate_kernels(impl):
             "_compare(cam,sc,up,sem,var,None);"
             "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
             "for n in ('scannet_tree_k16','generic_k5_white_bg','plain_mask','huge_splats','deep_tiles_3000','large_tree_k74')];print('ok')")
-    env = dict(os.environ, HSR_BWD_IMPL=impl, HSR_FWD_IMPL=impl)
+    env = _ablate_env(HSR_BWD_IMPL=impl) if impl == "mfma" else dict(os.environ, HSR_BWD_IMPL=impl, HSR_FWD_IMPL=impl)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
@@ -194,9 +205,22 @@ def test_parity_wide_tree_kernel_selectors():
             "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
             "for n in ('generic_k40_two_chunks','large_tree_k74','flat_k102','odd_k33','odd_k75_ragged','k52_four_column_groups','k124_widest_single_pass','k130_chunked','wide_deep_tiles_k76')];print('ok')")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # + the K = 74 forward with its rows parked in registers, + the matrix-core forward in its round-1 range (29..124)
-    for extra in (dict(HSR_BWD_WIDE_PASS="split"), dict(HSR_BWD_WIDE_MMA="f32"), dict(HSR_FWD_PF="0"), dict(HSR_FWD_IMPL="wide")):
+    # + the K = 74 forward with its rows parked in registers
+    for extra in (dict(HSR_BWD_WIDE_PASS="split"), dict(HSR_BWD_WIDE_MMA="f32"), dict(HSR_FWD_PF="0")):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_parity_round1_wide_kernels_in_the_ablate_build():
+    """round 1's matrix-core forward (29 <= K <= 124) and quadrant-list wide backward: csrc/experiments/, ablate build only"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0]=['hier-slam_amd','tests'];import scenes;from test_gpu_parity import CASES,_compare;"
+            "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
+            "for n in ('generic_k40_two_chunks','large_tree_k74','flat_k102','odd_k33','odd_k75_ragged','k124_widest_single_pass','wide_deep_tiles_k76')];print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (dict(HSR_FWD_IMPL="wide"), dict(HSR_BWD_IMPL="mfma")):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=_ablate_env(**extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
 
 

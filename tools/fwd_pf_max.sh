@@ -1,5 +1,7 @@
 #!/bin/bash
 # experiment: the per-lane (PF, quad-shared rows) forward beyond 80 channels vs the matrix-core forward (hsr_render_fwd_wide.hip)
+# (since round 3 HSR_BWD_IMPL=mfma / HSR_FWD_IMPL=wide exist in the ablate build only: `make -C hier-slam_amd/csrc ablate`)
+export HSR_RAST_LIB=${HSR_RAST_LIB:-$PWD/hier-slam_amd/libhsr_rast_ablate.so} HSR_GLUE=ctypes
 cd $GRAFT_REPO_ROOT
 for mode in wide_mfma per_lane; do
   for K in 90 102 124; do  # (the per_lane rows need HSR_FWD_PF_MAX, an experiment switch that was removed when the result became the default)
