@@ -6,6 +6,8 @@
     cat_params_to_optimizer(new_params, params, optimizer)            :121-137
     update_params_and_optimizer(new_params, params, optimizer)        :107-119
     inverse_sigmoid, accumulate_mean2d_gradient                       :163-164, :100-104
+    densify(params, variables, optimizer, iter, densify_dict)         :191-242   (gradient-driven clone / split / prune; off in the
+                                                                                   reference's configs, kept for callers that enable it)
 
 The reference prunes with ~22 boolean-mask gathers (six parameters, two Adam moments each, four bookkeeping vectors), each
 with its own nonzero() and host sync, and concatenates tensor by tensor.  Here every per-Gaussian tensor is a row table of
@@ -229,3 +231,91 @@ def accumulate_mean2d_gradient(variables):
     variables['means2D_gradient_accum'][variables['seen']] += torch.norm(variables['means2D'].grad[variables['seen'], :2], dim=-1)
     variables['denom'][variables['seen']] += 1
     return variables
+
+
+def _rotate_by_quaternion(q, v):
+    """R(q / |q|) v for rows of quaternions (r, x, y, z) and vectors: v + 2 r (u x v) + 2 u x (u x v), u = (x, y, z)"""
+    q = q / q.norm(dim=1, keepdim=True)
+    r, u = q[:, :1], q[:, 1:]
+    c = torch.cross(u, v, dim=1)
+    return v + 2.0 * (r * c + torch.cross(u, c, dim=1))
+
+
+def densify(params, variables, optimizer, iter, densify_dict):
+    """utils/slam_external.py:191-242 — the 3DGS-style densification the reference keeps behind `use_gaussian_splatting_densification`
+    (False in its configs): while iter <= stop_after the image-plane gradient norm of every seen Gaussian is accumulated; on a
+    densification iteration (iter >= start_after, every densify_every) Gaussians whose mean accumulated gradient reaches grad_thresh are
+    CLONED when small (largest scale <= 1 % of the scene radius) or SPLIT into num_to_split_into samples of themselves when large (means
+    drawn from the Gaussian itself, scales divided by 0.8 n, the original removed), then everything below the opacity threshold — and,
+    from remove_big_after on, above 10 % of the scene radius — is pruned and the accumulators restart; opacities are reset on their own
+    schedule.  Same keys, same order of the resulting rows (kept originals, clones, splits) and the same single `torch.normal` draw as
+    the reference, so a seeded run consumes the generator identically.
+
+    Where the reference runs three concatenations and two removals tensor by tensor (each with its own mask gathers and host syncs),
+    this decides every row's fate first and runs ONE fused compaction + append over all parameters, Adam moments and bookkeeping vectors
+    (appended rows get zero moments, like `cat_params_to_optimizer`).  `variables['timestep']`, which the reference's version cannot
+    carry through its concatenations, is inherited from the source Gaussian."""
+    if iter > densify_dict['stop_after']:
+        return params, variables
+    variables = accumulate_mean2d_gradient(variables)
+    if iter >= densify_dict['start_after'] and iter % densify_dict['densify_every'] == 0:
+        with torch.no_grad():
+            n = int(densify_dict['num_to_split_into'])
+            radius = variables['scene_radius']
+            mean_grad = variables['means2D_gradient_accum'] / variables['denom']
+            mean_grad = torch.where(torch.isnan(mean_grad), torch.zeros_like(mean_grad), mean_grad)
+            extent = torch.exp(params['log_scales']).max(dim=1).values
+            hot = mean_grad >= densify_dict['grad_thresh']
+            small = extent <= 0.01 * radius
+            cloned, split = hot & small, hot & ~small
+            opacity_floor = (densify_dict['final_removal_opacity_threshold'] if iter == densify_dict['stop_after']
+                             else densify_dict['removal_opacity_threshold'])
+            cull_big = iter >= densify_dict['remove_big_after']
+
+            def doomed(logit_opacities, log_scales):   # the closing prune, applied to whatever set of rows
+                out = (torch.sigmoid(logit_opacities) < opacity_floor).reshape(-1)
+                if cull_big:
+                    out = out | (torch.exp(log_scales).max(dim=1).values > 0.1 * radius)
+                return out
+
+            gaussian_keys = [k for k in params.keys() if k not in CAMERA_KEYS]
+            fresh = {}
+            for k in gaussian_keys:
+                v = params[k].detach()
+                fresh[k] = torch.cat((v[cloned], v[split].repeat(n, *([1] * (v.dim() - 1)))), dim=0)
+            n_clone, n_split = int(cloned.sum()), int(split.sum())
+            if n_split:
+                sigma = torch.exp(params['log_scales'].detach()[split])
+                sigma = (sigma.expand(-1, 3) if sigma.shape[1] == 1 else sigma).repeat(n, 1)
+                offsets = torch.normal(mean=torch.zeros_like(sigma), std=sigma)
+                turn = params['unnorm_rotations'].detach()[split].repeat(n, 1)
+                fresh['means3D'][n_clone:] += _rotate_by_quaternion(turn, offsets)
+                fresh['log_scales'][n_clone:] = torch.log(torch.exp(fresh['log_scales'][n_clone:]) / (0.8 * n))
+            stays = ~doomed(fresh['logit_opacities'], fresh['log_scales'])
+            fresh = {k: v[stays].contiguous() for k, v in fresh.items()}
+            n_new = int(stays.sum())
+            keep = (~split & ~doomed(params['logit_opacities'].detach(), params['log_scales'].detach())).to(torch.uint8).contiguous()
+
+            names, tensors = _gaussian_tables(params, variables, optimizer)
+            source_time = None
+            if 'timestep' in variables and torch.is_tensor(variables['timestep']):
+                t = variables['timestep']
+                source_time = torch.cat((t[cloned], t[split].repeat(n)))[stays].to(torch.float32).contiguous()
+            appended = []
+            for kind, k in names:
+                if kind == "param":
+                    appended.append(fresh[k])
+                elif kind == "var" and k == 'timestep':
+                    appended.append(source_time)
+                else:
+                    appended.append(None)      # Adam moments and accumulators of new rows start at zero
+            new = compact_append(tensors, keep=keep, appended=appended, n_append=n_new)
+            _install(names, new, params, variables, optimizer)
+            rows = int(params['means3D'].shape[0])
+            dev = params['means3D'].device
+            for k in ('means2D_gradient_accum', 'denom', 'max_2D_radius'):
+                variables[k] = torch.zeros(rows, device=dev)
+    if iter > 0 and iter % densify_dict['reset_opacities_every'] == 0 and densify_dict['reset_opacities']:
+        params = update_params_and_optimizer({'logit_opacities': inverse_sigmoid(torch.full_like(params['logit_opacities'], 0.01))},
+                                             params, optimizer)
+    return params, variables

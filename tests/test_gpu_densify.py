@@ -231,3 +231,113 @@ def test_remove_points_with_a_caller_mask_and_bad_input():
     all_gone = torch.ones(params["means3D"].shape[0], dtype=torch.bool, device="cuda")
     p2, v2 = SE.remove_points(all_gone, params, variables, opt)
     assert p2["means3D"].shape == (0, 3) and v2["timestep"].shape == (0,)
+
+
+# ---- gradient-driven densification (utils/slam_external.py:191-242; off in the reference's configs).  The reference's function hard-codes
+# device="cuda" and this container has no GPU, so no fixture of its own outputs can be made: REFERENCE-UNPINNED.  The check is a step-by-step
+# torch restatement of the documented sequence (accumulate, clone-concat, split-concat, remove the split originals, prune, reset), written
+# here with plain concatenations and boolean indexing, seeded identically (both sides draw ONE torch.normal of the same shape). ----
+def _densify_stepwise(params, moments, variables, it, dd, grad2d, seen):
+    """dicts of plain tensors in, dicts out; `moments[k]` = (exp_avg, exp_avg_sq)"""
+    keys = list(KEYS)
+    acc, den = variables["means2D_gradient_accum"].clone(), variables["denom"].clone()
+    acc[seen] += grad2d[seen, :2].norm(dim=-1)
+    den[seen] += 1
+    out_vars = dict(variables, means2D_gradient_accum=acc, denom=den)
+    if it >= dd["start_after"] and it % dd["densify_every"] == 0:
+        g = acc / den
+        g[g.isnan()] = 0.0
+        R = variables["scene_radius"]
+        big = lambda ls: torch.exp(ls).max(dim=1).values
+        clone = (g >= dd["grad_thresh"]) & (big(params["log_scales"]) <= 0.01 * R)
+        P0 = params["means3D"].shape[0]
+        cat = lambda d, new: {k: torch.cat((d[k], new[k])) for k in keys}
+        zeros_like_rows = lambda new: {k: (torch.zeros_like(new[k]), torch.zeros_like(new[k])) for k in keys}
+        catm = lambda m, z: {k: (torch.cat((m[k][0], z[k][0])), torch.cat((m[k][1], z[k][1]))) for k in keys}
+        new = {k: params[k][clone] for k in keys}
+        tstep = torch.cat((variables["timestep"], variables["timestep"][clone]))
+        params, moments = cat(params, new), catm(moments, zeros_like_rows(new))
+        P1 = params["means3D"].shape[0]
+        gp = torch.zeros(P1, device=g.device)
+        gp[:P0] = g
+        split = (gp >= dd["grad_thresh"]) & (big(params["log_scales"]) > 0.01 * R)
+        n = dd["num_to_split_into"]
+        new = {k: params[k][split].repeat(n, 1) for k in keys}
+        std = torch.exp(params["log_scales"])[split]
+        std = (std if std.shape[1] == 3 else std.repeat(1, 3)).repeat(n, 1)
+        samples = torch.normal(mean=torch.zeros_like(std), std=std)
+        q = torch.nn.functional.normalize(params["unnorm_rotations"][split]).repeat(n, 1)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        rot = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                           2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                           2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+        new["means3D"] = new["means3D"] + torch.bmm(rot, samples.unsqueeze(-1)).squeeze(-1)
+        new["log_scales"] = torch.log(torch.exp(new["log_scales"]) / (0.8 * n))
+        tstep = torch.cat((tstep, tstep[split].repeat(n)))
+        params, moments = cat(params, new), catm(moments, zeros_like_rows(new))
+        P2 = params["means3D"].shape[0]
+        gone = torch.cat((split, torch.zeros(P2 - P1, dtype=torch.bool, device=split.device)))
+        take = lambda keep: ({k: params[k][keep] for k in keys}, {k: (moments[k][0][keep], moments[k][1][keep]) for k in keys})
+        params, moments = take(~gone)
+        tstep = tstep[~gone]
+        thr = dd["final_removal_opacity_threshold"] if it == dd["stop_after"] else dd["removal_opacity_threshold"]
+        gone = (torch.sigmoid(params["logit_opacities"]) < thr).squeeze(-1)
+        if it >= dd["remove_big_after"]:
+            gone = gone | (big(params["log_scales"]) > 0.1 * R)
+        params, moments = take(~gone)
+        tstep = tstep[~gone]
+        rows = params["means3D"].shape[0]
+        zero = torch.zeros(rows, device=g.device)
+        out_vars = dict(variables, means2D_gradient_accum=zero, denom=zero.clone(), max_2D_radius=zero.clone(), timestep=tstep,
+                        _counts=(int(clone.sum()), int(split.sum()), P2 - int(gone.sum()) - int(split.sum()) - rows + int(gone.sum())))
+    if it > 0 and it % dd["reset_opacities_every"] == 0 and dd["reset_opacities"]:
+        params = dict(params, logit_opacities=torch.log(torch.full_like(params["logit_opacities"], 0.01) / 0.99))
+        moments = dict(moments, logit_opacities=(torch.zeros_like(params["logit_opacities"]), torch.zeros_like(params["logit_opacities"])))
+    return params, moments, out_vars
+
+
+@pytest.mark.parametrize("it, remove_big, reset", [(100, False, False), (300, True, False), (500, True, True), (150, False, False),
+                                                    (700, False, False)])
+def test_gradient_driven_densify_matches_its_stepwise_restatement(it, remove_big, reset):
+    from hsr_utils import slam_external as SE
+    z = np.load(GOLD, allow_pickle=False)
+    params, variables, opt = _load_state(z, "prune_iter0/in")
+    P = params["means3D"].shape[0]
+    g = torch.Generator().manual_seed(it)
+    variables["means2D_gradient_accum"] = (torch.rand(P, generator=g) * 2e-3).cuda()
+    variables["denom"] = torch.randint(0, 4, (P,), generator=g).float().cuda()       # zeros -> 0/0 = NaN -> 0
+    variables["seen"] = (torch.rand(P, generator=g) < 0.6).cuda()
+    variables["scene_radius"] = torch.tensor(float(torch.exp(params["log_scales"].detach()).max(dim=1).values.median()) / 0.01 * 1.0).cuda()
+    m2d = torch.zeros(P, 3, device="cuda", requires_grad=True)
+    m2d.grad = (torch.randn(P, 3, generator=g) * 1e-3).cuda()
+    variables["means2D"] = m2d
+    dd = dict(start_after=100, remove_big_after=300, stop_after=500, densify_every=100, grad_thresh=6e-4, num_to_split_into=2,
+              removal_opacity_threshold=0.3, final_removal_opacity_threshold=0.5, reset_opacities=reset, reset_opacities_every=250)
+    plain = {k: params[k].detach().clone() for k in KEYS}
+    mom = {k: (opt.state[params[k]]["exp_avg"].clone(), opt.state[params[k]]["exp_avg_sq"].clone()) for k in KEYS}
+    var0 = {k: (v.clone() if torch.is_tensor(v) and k != "means2D" else v) for k, v in variables.items()}
+    torch.manual_seed(1234)
+    exp_p, exp_m, exp_v = _densify_stepwise(plain, mom, var0, it, dd, m2d.grad, variables["seen"])
+    torch.manual_seed(1234)
+    params, variables = SE.densify(params, variables, opt, it, dd)
+    if it > dd["stop_after"]:
+        assert params["means3D"].shape[0] == P and torch.equal(variables["denom"], var0["denom"])      # nothing happens any more
+        return
+    assert params["means3D"].shape[0] == exp_p["means3D"].shape[0]
+    if it % 100 == 0:
+        n_clone, n_split, _ = exp_v["_counts"]
+        assert n_clone > 20 and n_split > 20 and params["means3D"].shape[0] < P + n_clone + n_split   # it really clones, splits and prunes
+    for k in KEYS:
+        a, e = params[k].detach(), exp_p[k]
+        if k == "means3D":
+            assert torch.allclose(a, e, rtol=0, atol=2e-6 * float(e.abs().max())), k     # R v by cross products vs by a rotation matrix
+        else:
+            assert torch.equal(a, e), k
+        st = opt.state[params[k]]
+        assert torch.equal(st["exp_avg"], exp_m[k][0]) and torch.equal(st["exp_avg_sq"], exp_m[k][1]), k
+        assert [g_ for g_ in opt.param_groups if g_["name"] == k][0]["params"][0] is params[k]
+    for k in ("means2D_gradient_accum", "denom", "max_2D_radius", "timestep"):
+        assert torch.equal(variables[k], exp_v[k]), k
+    assert params["cam_trans"].shape == (1, 3, 5)
+    (params["means3D"].sum() + params["semantic"].sum()).backward()      # the densified map still trains through the re-keyed state
+    opt.step()
