@@ -177,6 +177,7 @@ struct RenderFwdArgs {
     BinDevRef bin;    // base != NULL: point_list is resolved on the device (speculative forward)
 };
 int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream);
+bool hsr_launch_render_forward_mma(const RenderFwdArgs& a, hipStream_t stream);   // experiments/ (ablate build): semantic, K <= 140, channel sums on the fp32 matrix cores
 bool hsr_launch_render_forward_wide(const RenderFwdArgs& a, hipStream_t stream);  // experiments/ (ablate build): semantic, 29 <= K <= 124; false otherwise
 
 struct RenderBwdArgs {

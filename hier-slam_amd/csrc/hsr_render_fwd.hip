@@ -616,6 +616,12 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     // entry has to go through the pair; removed in round 3 — it predates the saved sub-block masks and median positions the backward reads).
     static const char* impl = getenv("HSR_FWD_IMPL");
     static const bool force_valu = impl && !strcmp(impl, "valu");   // quadrant lists, per-lane accumulators for every K
+#ifdef HSR_ABLATE
+    // round 3's sub-block forward with the channel sums on the fp32 matrix cores (experiments/hsr_render_fwd_mma.hip): parity-green and
+    // slower at every width — fp32 MFMA and plain VALU FMA both run ~34 MAC per cycle and SIMD (EXPERIMENTS.md §9b)
+    static const bool use_mma = impl && !strcmp(impl, "mma");
+    if (use_mma && hsr_launch_render_forward_mma(a, stream)) return HSR_OK;
+#endif
     if (!a.semantic) {
         if (force_valu) render_fwd_kernel<0, true, true, false, false><<<grid, block, 0, stream>>>(a, 0);
         else render_fwd_kernel<0, true, true, false, true><<<grid, block, 0, stream>>>(a, 0);

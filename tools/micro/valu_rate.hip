@@ -15,6 +15,7 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 // MODE 0: 16 independent v_fma_f32 per iteration     1: 8 independent v_pk_fma_f32 (16 lanes-worth of fma each... 2 fma/lane)
 // MODE 2: 16 independent v_exp_f32                   3: 4 independent v_mfma_f32_16x16x4_f32
 // MODE 4: 4 MFMA + 16 v_fma interleaved 1:4          5: 4 MFMA + 32 v_fma interleaved 1:8
+// MODE 8: 16 independent v_fmac_f32_dpp (quad_perm)   9: 16 independent v_fmac_f32
 // MODE 6: 4 independent v_mfma_f32_16x16x32_bf16     7: 4 bf16 MFMA + 32 v_fma interleaved 1:8   (the 3 x bf16 split of an fp32 product)
 template <int MODE>
 __global__ void k(float* out, unsigned long long* cyc, int iters)
@@ -43,6 +44,13 @@ __global__ void k(float* out, unsigned long long* cyc, int iters)
         } else if (MODE == 2) {
 #pragma unroll
             for (int i = 0; i < 16; i++) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+        } else if (MODE == 8) {   // the wide forward's accumulate: the feature comes from a quad lane through the FMA's DPP operand
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(m), "v"(c));
+        } else if (MODE == 9) {   // the same without DPP
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
         } else if (MODE == 3) {
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], a[i + 4], acc[i], 0, 0, 0);
@@ -108,7 +116,9 @@ template <int MODE> void run(const char* name, int waves_per_simd, double valu_p
 
 int main()
 {
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2, 3, 4}) {
+        run<8>("v_fmac_f32_dpp quad_perm x16 independent", w, 16, 0);
+        run<9>("v_fmac_f32 x16 independent", w, 16, 0);
         run<0>("v_fma_f32 x16 independent", w, 16, 0);
         run<1>("v_pk_fma_f32 x8 independent", w, 8, 0);
         run<2>("v_exp_f32 x16 independent", w, 16, 0);
