@@ -531,11 +531,17 @@ def main():
                 wl = Workload(dev, w_, h_, p_, k_, kind_, 0, 1)
                 dgr.set_async_forward(ahead)
                 try:
-                    r2 = wl.run(max(20, args.workload_steps), 5, profile=not args.no_profile, lib=_C._lib)
+                    # small workloads take a fraction of a millisecond per step: enough steps for ~50 ms of timed region, and the better
+                    # of two timed regions (the first one of a new size also pays the allocator's growth)
+                    n_steps = max(20, args.workload_steps) * (1 if p_ >= 1000000 else (3 if p_ >= 300000 else 6))
+                    r2 = wl.run(n_steps, 5, profile=not args.no_profile, lib=_C._lib)
+                    r3 = wl.run(n_steps, 0, profile=False, lib=_C._lib)
+                    if r3["elapsed"] / r3["steps"] < r2["elapsed"] / r2["steps"]:
+                        r2["elapsed"], r2["steps"], r2["host_wait_ms"] = r3["elapsed"], r3["steps"], r3["host_wait_ms"]
                 finally:
                     dgr.set_async_forward(False)
                 e = {"workload": wl.describe(), "tag": tag, "renders_s": r2["steps"] / r2["elapsed"], "ms_per_step": 1e3 * r2["elapsed"] / r2["steps"],
-                     "steps": r2["steps"], "visible": r2["V"], "num_rendered": r2["R"],
+                     "steps": r2["steps"], "timing": "better of two timed regions", "visible": r2["V"], "num_rendered": r2["R"],
                      "host_blocked_on_device_ms_per_step": round(r2["host_wait_ms"], 4)}
                 if r2.get("stages"):
                     d_ = r2["dominant"]
