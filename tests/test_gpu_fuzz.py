@@ -40,6 +40,20 @@ def test_random_configuration(name, cfg):
     _compare(cam, sc, up, semantic, variant, None)
 
 
+# the legacy accumulation mode (no scratch: atomics straight into the reference's six arrays) runs the all-VALU quadrant-list backward
+# (hsr_render_bwd.hip) since round 3: every third case of the default list through it
+@pytest.mark.parametrize("name,cfg", CASES[::3], ids=[c[0] for c in CASES[::3]])
+def test_random_configuration_legacy_accumulation(name, cfg):
+    from diff_gaussian_rasterization import _C
+    W, H, P, K, kind, sm, semantic, variant, bg, behind = cfg
+    cam, sc, up = scenes.build(W, H, P, K, seed=zlib.crc32(name.encode()) % 1000, kind=kind, scale_mult=sm, bg=bg, behind_frac=behind)
+    _C.set_backward_mode("legacy")
+    try:
+        _compare(cam, sc, up, semantic, variant, None)
+    finally:
+        _C.set_backward_mode("packed")
+
+
 # cases of the 300-case run with seed 77 that found a bug: wide-tree forward kernels left the feature row of batch slot 0 unstaged when
 # no sub-block of the tile visits that splat, and a 16-lane group with an EMPTY list reads slot 0 with weight 0 — NaN * 0 when the LDS
 # still held the per-tile sort's ~0 padding
