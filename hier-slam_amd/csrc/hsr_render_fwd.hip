@@ -611,11 +611,15 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     const dim3 grid(hsr_tile_grid(tiles)), block(256);
     // Default for K <= 28: the per-lane kernel on 4x4 sub-block lists (SUB).  Measured at the headline workload (500k
     // Gaussians, 1200x680, K = 26): 0.18 ms against 0.22 ms for the same kernel on quadrant lists (HSR_FWD_IMPL=valu, kept
-    // for A/B timing and tests) and 0.27 ms for round 1's pair-pipelined matrix-core kernel (EXPERIMENTS.md §4: the ~25 VALU
+    // in the ablate build for A/B timing) and 0.27 ms for round 1's pair-pipelined matrix-core kernel (EXPERIMENTS.md §4: the ~25 VALU
     // instructions that evaluate alpha per list entry dominate, the matrix cores only take the 15 packed FMAs behind them, and every list
     // entry has to go through the pair; removed in round 3 — it predates the saved sub-block masks and median positions the backward reads).
+#ifdef HSR_ABLATE
     static const char* impl = getenv("HSR_FWD_IMPL");
-    static const bool force_valu = impl && !strcmp(impl, "valu");   // quadrant lists, per-lane accumulators for every K
+    static const bool force_valu = impl && !strcmp(impl, "valu");   // quadrant lists, per-lane accumulators for every K: ablate build only
+#else
+    constexpr bool force_valu = false;   // the product renders on sub-block lists; HSR_FWD_IMPL selects nothing here
+#endif
 #ifdef HSR_ABLATE
     // round 3's sub-block forward with the channel sums on the fp32 matrix cores (experiments/hsr_render_fwd_mma.hip): parity-green and
     // slower at every width — fp32 MFMA and plain VALU FMA both run ~34 MAC per cycle and SIMD (EXPERIMENTS.md §9b)
@@ -623,8 +627,13 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
     if (use_mma && hsr_launch_render_forward_mma(a, stream)) return HSR_OK;
 #endif
     if (!a.semantic) {
-        if (force_valu) render_fwd_kernel<0, true, true, false, false><<<grid, block, 0, stream>>>(a, 0);
-        else render_fwd_kernel<0, true, true, false, true><<<grid, block, 0, stream>>>(a, 0);
+#ifdef HSR_ABLATE
+        if (force_valu) {
+            render_fwd_kernel<0, true, true, false, false><<<grid, block, 0, stream>>>(a, 0);
+            return HSR_OK;
+        }
+#endif
+        render_fwd_kernel<0, true, true, false, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;
     }
     // Wide trees.  Round 1 accumulated 29 <= K <= 124 on the matrix cores (experiments/hsr_render_fwd_wide.hip; HSR_FWD_IMPL=wide in the
@@ -668,6 +677,7 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
             return HSR_OK;
         }
     }
+#ifdef HSR_ABLATE
     // HSR_FWD_IMPL=valu: quadrant lists, per-lane accumulators
     switch (a.K) {
     case 0: render_fwd_kernel<0, true, false, false><<<grid, block, 0, stream>>>(a, 0); break;
@@ -681,5 +691,6 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
         for (int c0 = 32; c0 < a.K; c0 += 32) render_fwd_kernel<32, false, false, false><<<grid, block, 0, stream>>>(a, c0);
         break;
     }
+#endif
     return HSR_OK;
 }

@@ -188,7 +188,9 @@ def test_parity_alternate_kernels(impl):
             "_compare(cam,sc,up,sem,var,None);"
             "[_compare(*((lambda W,H,P,K,kind,sm,sem,var,bg,beh: (lambda csu: (csu[0],csu[1],csu[2],sem,var,None))(scenes.build(W,H,P,K,seed=11,kind=kind,scale_mult=sm,bg=bg,behind_frac=beh)))(*CASES[n]))) "
             "for n in ('scannet_tree_k16','generic_k5_white_bg','plain_mask','huge_splats','deep_tiles_3000','large_tree_k74')];print('ok')")
-    env = _ablate_env(HSR_BWD_IMPL=impl) if impl == "mfma" else dict(os.environ, HSR_BWD_IMPL=impl, HSR_FWD_IMPL=impl)
+    # "valu": the all-VALU backward in the PRODUCT library (its fallback kernel); the quadrant-list forward of the same name exists in
+    # the ablate build only and is covered by test_parity_round1_wide_kernels_in_the_ablate_build
+    env = _ablate_env(HSR_BWD_IMPL=impl) if impl == "mfma" else dict(os.environ, HSR_BWD_IMPL=impl)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
@@ -220,7 +222,7 @@ def test_parity_round1_wide_kernels_in_the_ablate_build():
             "for n in ('generic_k40_two_chunks','large_tree_k74','flat_k102','odd_k33','odd_k75_ragged','k124_widest_single_pass','wide_deep_tiles_k76')];print('ok')")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # + round 3's sub-block forward on the fp32 matrix cores (hsr_render_fwd_mma.hip)
-    for extra in (dict(HSR_FWD_IMPL="wide"), dict(HSR_BWD_IMPL="mfma"), dict(HSR_FWD_IMPL="mma")):
+    for extra in (dict(HSR_FWD_IMPL="wide"), dict(HSR_BWD_IMPL="mfma"), dict(HSR_FWD_IMPL="mma"), dict(HSR_FWD_IMPL="valu")):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=_ablate_env(**extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
 
