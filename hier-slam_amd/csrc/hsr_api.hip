@@ -211,7 +211,15 @@ int poll_counter(uint32_t seq, hipStream_t stream, uint32_t* host_out, volatile 
     const auto t0 = std::chrono::steady_clock::now();
     if (slot) {   // a ring slot of the non-blocking forward (may be resolved on another thread: no per-thread back-off state)
         unsigned spins = 0;
-        while (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) != seq) {
+        uint32_t cur;
+        while ((cur = __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE)) != seq) {
+            // sequence numbers of a device only grow: a LATER one in this slot means HSR_ASYNC_SLOTS further non-blocking forwards were
+            // started on the device before this one was resolved, and its count has been overwritten
+            if (cur != 0 && (int32_t)(cur - seq) > 0) {
+                hsr_set_error("non-blocking forward: this call's num_rendered was overwritten — more than %d non-blocking forwards were "
+                              "started on the device before it was resolved (resolve or drop earlier ones first)", HSR_ASYNC_SLOTS - 1);
+                return HSR_ERR_INVALID_ARGUMENT;
+            }
             if ((++spins & 0xFFFu) == 0) {
                 const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (el > 10.0) {
@@ -912,7 +920,10 @@ int hsr_forward_end(hsr_ticket* ticket, int block, void* stream)
         hsr_set_error("hsr_forward_end: the ticket does not belong to a forward call that ran ahead");
         return HSR_ERR_INVALID_ARGUMENT;
     }
-    if (!block && __atomic_load_n(&ticket->slot[1], __ATOMIC_ACQUIRE) != ticket->seq) return HSR_PENDING;
+    if (!block) {
+        const uint32_t cur = __atomic_load_n(&ticket->slot[1], __ATOMIC_ACQUIRE);
+        if (cur != ticket->seq && !(cur != 0 && (int32_t)(cur - ticket->seq) > 0)) return HSR_PENDING;   // (overwritten: reported below)
+    }
     uint32_t R32 = 0;
     int rc;
     if ((rc = poll_counter(ticket->seq, static_cast<hipStream_t>(stream), &R32, ticket->slot)) != HSR_OK) return rc;

@@ -122,7 +122,9 @@ int hsr_forward_semantic(hsr_buffer* geometry, hsr_buffer* binning, hsr_buffer* 
  * num_rendered; the ticket then has seq == 0.  If num_rendered turns out NOT to fit the binning buffer the device kernels that
  * depend on it do nothing except fill the output images with NaN, hsr_forward_end returns HSR_ERR_BUFFER_TOO_SMALL (ticket->rendered
  * holds the count) and the caller must run the forward again with a larger buffer: everything computed from those outputs in
- * between is invalid — which is why this is opt-in and the Python layer raises (diff_gaussian_rasterization.set_async_forward). */
+ * between is invalid — which is why this is opt-in and the Python layer raises (diff_gaussian_rasterization.set_async_forward).
+ * Counts live in a ring of 256 host-mapped slots per device: a ticket that is still unresolved when 256 later non-blocking forwards
+ * have started on its device has lost its count, and hsr_forward_end says so at once (HSR_ERR_INVALID_ARGUMENT, "overwritten"). */
 #define HSR_PENDING (-100)
 typedef struct hsr_ticket {
     uint32_t seq;                 /* 0: the armed call did not run ahead (it returned num_rendered itself) */

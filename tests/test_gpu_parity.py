@@ -544,3 +544,35 @@ def test_non_blocking_forward_runs_ahead_and_fails_loudly_when_the_buffer_was_to
         assert torch.equal(outs[0].detach(), ref[0][0]) and int(outs[0].grad_fn.num_rendered) == R
     finally:
         dgr.set_async_forward(prev)
+
+
+def test_non_blocking_count_overwritten_after_a_ring_of_unresolved_forwards_fails_at_once():
+    """The non-blocking forward's counts live in a ring of 256 host-mapped slots per device.  A forward whose count nobody resolved
+    while 256 later ones ran ahead has lost it: resolving it then must raise immediately (not wait 10 s for a sequence number that
+    will never come back), later forwards are unaffected."""
+    import time
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    W, H, P, K = 64, 48, 400, 5
+    cam, sc, up = scenes.build(W, H, P, K, seed=3, kind="slam")
+    _fwd_bwd(cam, sc, up, dev)                        # blocking; leaves the binning hint of this size
+    prev = dgr.set_async_forward(True)
+    try:
+        leaf0, outs0 = _render_sem(cam, sc, dev)      # never resolved ...
+        first = outs0[0].grad_fn.num_rendered
+        assert isinstance(first, _C.LazyRendered)
+        for _ in range(260):                          # ... while a whole ring of later forwards runs ahead (each resolved by its backward)
+            leaf, outs = _render_sem(cam, sc, dev)
+            outs[0].sum().backward()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="overwritten"):
+            outs0[0].sum().backward()
+        assert time.perf_counter() - t0 < 2.0
+        leaf, outs = _render_sem(cam, sc, dev)        # the ring itself is fine
+        outs[0].sum().backward()
+        torch.cuda.synchronize()
+        assert int(outs[0].grad_fn.num_rendered) > 0 and torch.isfinite(leaf["means3D"].grad).all()
+    finally:
+        dgr.set_async_forward(prev)
