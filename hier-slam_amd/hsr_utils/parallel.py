@@ -251,6 +251,11 @@ class GradientExchange:
             self._stats["bytes_exchanged"] += dense_bytes
             return b
         U = int(idx.numel())
+        if U == 0:
+            # no rank saw anything: every gradient row is zero everywhere, so is the sum — no collective (the same decision on every
+            # rank: the mask is the all-reduced one), and no zero-length all-reduce for the backend to trip over
+            self._stats["sparse_steps"] += 1
+            return b
         widths = [n // self.P for n in bucket.sizes]
         compact = torch.empty(U * sum(widths), dtype=bucket.flat.dtype, device=bucket.flat.device)
         parts, off = [], 0

@@ -111,10 +111,10 @@ def _exchange_checks(rank, world):
               "raster.opacities": torch.zeros(P, 1, requires_grad=True)}
     ex = GradientExchange(leaves, "cpu", depth=2, sparse=True, dense_above=0.9)
     ref_leaves = [torch.zeros_like(t).requires_grad_(True) for t in leaves.values()]
-    views = {0: [(0, 120), (0, 200), (10, 60)], 1: [(80, 160), (0, 200), (50, 90)]}      # rows each rank sees, per step
-    expect_sparse = [True, False, True]                                                    # union 160 / 200 / 80 of 200 rows
+    views = {0: [(0, 120), (0, 200), (10, 60), (0, 0)], 1: [(80, 160), (0, 200), (50, 90), (0, 0)]}      # rows each rank sees, per step
+    expect_sparse = [True, False, True, True]                                             # union 160 / 200 / 80 / 0 of 200 rows
     kept = {}
-    for step in range(3):
+    for step in range(4):
         lo, hi = views[rank][step]
         radii = torch.zeros(P, dtype=torch.int32)
         radii[lo:hi] = 3
@@ -137,19 +137,19 @@ def _exchange_checks(rank, world):
         if step >= 1:                                 # the bucket of step - 1 is about to be reused: read it first
             for v, e in zip(ex.reduced(step - 1), kept[step - 1]):
                 assert torch.equal(v, e), "sparse exchange of step %d differs from the dense sum" % (step - 1)
-    for v, e in zip(ex.reduced(2), kept[2]):
-        assert torch.equal(v, e)
+    for v, e in zip(ex.reduced(3), kept[3]):          # nothing visible anywhere: no collective, zeros
+        assert torch.equal(v, e) and not bool(v.any())
     ex.drain()
     st = ex.stats()
-    assert st["zero_copy_tensors"] == 9 and st["copied_tensors"] == 0
-    assert st["sparse_steps"] == 2 and st["bytes_exchanged"] < st["bytes_dense_equivalent"]
-    assert abs(st["union_fraction"] - (160 + 80) / (2 * 200)) < 1e-9
+    assert st["zero_copy_tensors"] == 12 and st["copied_tensors"] == 0
+    assert st["sparse_steps"] == 3 and st["bytes_exchanged"] < st["bytes_dense_equivalent"]
+    assert abs(st["union_fraction"] - (160 + 80 + 0) / (3 * 200)) < 1e-9
     # a gradient that did not come through the sink (another producer) is packed, not lost
     ex.begin_step(None)
     for t in leaves.values():
         t.grad = torch.full_like(t, float(rank + 1))
     ex.submit()
-    for v in ex.reduced(3):
+    for v in ex.reduced(4):
         assert torch.equal(v, torch.full_like(v, 3.0))
     assert ex.stats()["copied_tensors"] == 3
 
