@@ -27,6 +27,7 @@ CASES = {
     "k52_four_column_groups": (100, 70, 1500, 52, "aniso", 2.5, True, "sr", (0.1, 0.2, 0.3), 0.0),   # bf16-split contraction, 4 groups
     "k124_widest_single_pass": (64, 48, 600, 124, "slam", 3.0, True, "sr", (0, 0, 0), 0.0),
     "k130_chunked": (64, 48, 600, 130, "slam", 3.0, True, "sr", (0, 0, 0), 0.0),
+    "k257_many_chunks": (48, 40, 300, 257, "aniso", 3.0, True, "sr", (0.1, 0.0, 0.2), 0.0),   # 9 forward chunks, 4 backward passes, odd K
     "wide_deep_tiles_k76": (64, 48, 1500, 76, "aniso", 40.0, True, "sr", (0, 0, 0), 0.0),  # many batches, early termination
     "plain_mask": (144, 96, 2500, 0, "aniso", 2.0, False, "sr", (0, 0, 0), 0.0),
     "plain_cov3d": (96, 80, 1500, 0, "aniso", 2.0, False, "cov", (0, 0, 0), 0.0),
