@@ -577,3 +577,12 @@ def test_non_blocking_count_overwritten_after_a_ring_of_unresolved_forwards_fail
         assert int(outs[0].grad_fn.num_rendered) > 0 and torch.isfinite(leaf["means3D"].grad).all()
     finally:
         dgr.set_async_forward(prev)
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (3, 5), (16, 16), (17, 1), (1, 33), (15, 31)])
+def test_tiny_and_sliver_images(W, H):
+    """images smaller than a tile, exactly one tile, one pixel wide / high: ragged last tiles on both axes, sub-blocks entirely outside"""
+    cam, sc, up = scenes.build(W, H, 120, 6, seed=W * 100 + H, kind="aniso", scale_mult=4.0, bg=(0.2, 0.0, 0.1))
+    _compare(cam, sc, up, True, "sr", None)
+    cam, sc, up = scenes.build(W, H, 40, 0, seed=W * 100 + H + 1, kind="slam", scale_mult=6.0)
+    _compare(cam, sc, up, False, "sr", None)
