@@ -586,3 +586,39 @@ def test_tiny_and_sliver_images(W, H):
     _compare(cam, sc, up, True, "sr", None)
     cam, sc, up = scenes.build(W, H, 40, 0, seed=W * 100 + H + 1, kind="slam", scale_mult=6.0)
     _compare(cam, sc, up, False, "sr", None)
+
+
+def test_non_finite_gaussians_are_culled_and_harm_nothing():
+    """NaN positions / scales / rotations make a Gaussian's projected covariance NaN; like the reference's, the preprocess then ends with
+    radius 0 (ceil(NaN) converts to 0, the tile rectangle is empty) and the Gaussian takes no part: the render equals the render of the
+    map without those Gaussians bit for bit, their gradients are exactly zero, nobody else's are touched — and nothing hangs or faults."""
+    dev = torch.device("cuda:0")
+    W, H, P, K = 150, 90, 2500, 11
+    cam, sc, up = scenes.build(W, H, P, K, seed=21, kind="aniso", scale_mult=2.0)
+    g = torch.Generator().manual_seed(4)
+    bad = torch.rand(P, generator=g) < 0.04
+    which = torch.randint(0, 3, (P,), generator=g)
+    poisoned = {n: v.clone() for n, v in sc.items()}
+    nan = float("nan")
+    poisoned["means3D"][bad & (which == 0)] = nan
+    poisoned["scales"][bad & (which == 1), 1] = nan
+    poisoned["rotations"][bad & (which == 2), 2] = nan
+    clean = {n: (v[~bad].clone() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == P else v) for n, v in sc.items()}
+    lp, op = _render_sem(cam, poisoned, dev)
+    lc, oc = _render_sem(cam, clean, dev)
+    upd = {n: v.to(dev) for n, v in up.items()}
+    for outs in (op, oc):
+        color, radii, sem, depth, median, opac = outs
+        ((color * upd["color"]).sum() + (sem * upd["semantic"]).sum() + (depth * upd["depth"]).sum() + (median * upd["median"]).sum()
+         + (opac * upd["opacity"]).sum()).backward()
+    torch.cuda.synchronize()
+    badd = bad.to(dev)
+    assert int((op[1][badd] != 0).sum()) == 0 and torch.equal(op[1][~badd], oc[1])            # radii
+    for a, b in zip((op[0], op[2], op[3], op[4], op[5]), (oc[0], oc[2], oc[3], oc[4], oc[5])):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    for n in lp:
+        gp, gc = lp[n].grad, lc[n].grad
+        assert torch.isfinite(gp).all(), n
+        assert not bool(gp[badd].any()), n
+        # the survivors' sums are accumulated with float atomics in whatever order the tiles finish: same values up to that noise
+        assert float((gp[~badd] - gc).abs().max()) <= 1e-5 * max(1.0, float(gc.abs().max())), n
