@@ -36,6 +36,7 @@ CASES = {
     "semantic_k0": (64, 48, 500, 0, "aniso", 2.0, True, "sr", (0, 0, 0), 0.0),
     # > 2048 entries in every tile: the per-tile sort's block-radix fallback (and many staging batches per tile)
     "deep_tiles_3000": (64, 48, 3000, 16, "aniso", 40.0, True, "sr", (0, 0, 0), 0.0),
+    "deep_tiles_20000": (64, 48, 20000, 3, "aniso", 40.0, True, "sr", (0, 0, 0), 0.0),   # 20 000 entries in every tile: the in-tile radix sort, 80+ batches
     # BASELINE.json configs[0]: 256x256, 5k Gaussians, RGB + depth (the plain renderer), at its real size
     "config0_256x256_5k_plain": (256, 256, 5000, 0, "slam", 1.0, False, "sr", (0, 0, 0), 0.0),
     # BASELINE.json configs[3]'s frame: ScanNet 640x480, NYU40 tree K = 16 (one rank's keyframe of the 8-GPU batch)
