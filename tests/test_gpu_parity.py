@@ -623,3 +623,45 @@ def test_non_finite_gaussians_are_culled_and_harm_nothing():
         assert not bool(gp[badd].any()), n
         # the survivors' sums are accumulated with float atomics in whatever order the tiles finish: same values up to that noise
         assert float((gp[~badd] - gc).abs().max()) <= 1e-5 * max(1.0, float(gc.abs().max())), n
+
+
+def test_no_device_or_host_memory_growth_over_many_steps():
+    """600 forward+backward steps (blocking and non-blocking forward, stage timers on for a third of them): device memory allocated by
+    torch returns to where it was and the process's resident set stays put — no per-call leak in the glue, the library's event pool,
+    the host-mapped counters or the ticket ring."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    W, H, P, K = 160, 96, 3000, 16
+    cam, sc, up = scenes.build(W, H, P, K, seed=8, kind="slam")
+    upd = {n: v.to(dev) for n, v in up.items()}
+
+    def rss_mb():
+        with open("/proc/self/statm") as f:
+            return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2 ** 20
+
+    def step():
+        leaf, outs = _render_sem(cam, sc, dev)
+        color, radii, sem, depth, median, opac = outs
+        ((color * upd["color"]).sum() + (sem * upd["semantic"]).sum() + (depth * upd["depth"]).sum()).backward()
+    for _ in range(30):
+        step()
+    torch.cuda.synchronize()
+    mem0, rss0 = torch.cuda.memory_allocated(dev), rss_mb()
+    for phase in range(3):
+        prev = dgr.set_async_forward(phase == 1)
+        if phase == 2:
+            _C._lib.hsr_profile_enable(1)
+        try:
+            for _ in range(200):
+                step()
+            torch.cuda.synchronize()
+        finally:
+            dgr.set_async_forward(prev)
+            if phase == 2:
+                _C._lib.hsr_profile_read(None, 1)
+                _C._lib.hsr_profile_enable(0)
+    leaf = outs = None
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated(dev) <= mem0 + (1 << 20), (torch.cuda.memory_allocated(dev), mem0)
+    assert rss_mb() - rss0 < 64.0, (rss_mb(), rss0)
