@@ -341,3 +341,42 @@ def test_gradient_driven_densify_matches_its_stepwise_restatement(it, remove_big
     assert params["cam_trans"].shape == (1, 3, 5)
     (params["means3D"].sum() + params["semantic"].sum()).backward()      # the densified map still trains through the re-keyed state
     opt.step()
+
+
+@pytest.mark.parametrize("grad_thresh, removal, expect", [(1e9, 0.3, "prune_only"), (6e-4, 1.1, "empty_map"), (1e9, -1.0, "nothing")])
+def test_gradient_driven_densify_edge_cases(grad_thresh, removal, expect):
+    """nothing exceeds the gradient threshold (only the closing prune acts); every Gaussian falls below the opacity threshold (the
+    map becomes empty and still trains); neither (the map is unchanged, accumulators restart)"""
+    from hsr_utils import slam_external as SE
+    z = np.load(GOLD, allow_pickle=False)
+    params, variables, opt = _load_state(z, "prune_iter0/in")
+    P = params["means3D"].shape[0]
+    g = torch.Generator().manual_seed(9)
+    variables["means2D_gradient_accum"] = (torch.rand(P, generator=g) * 2e-3).cuda()
+    variables["denom"] = torch.randint(1, 4, (P,), generator=g).float().cuda()
+    variables["seen"] = (torch.rand(P, generator=g) < 0.6).cuda()
+    variables["scene_radius"] = torch.tensor(1e6).cuda()
+    m2d = torch.zeros(P, 3, device="cuda", requires_grad=True)
+    m2d.grad = (torch.randn(P, 3, generator=g) * 1e-3).cuda()
+    variables["means2D"] = m2d
+    before = {k: params[k].detach().clone() for k in KEYS}
+    op = torch.sigmoid(before["logit_opacities"]).squeeze(-1)
+    dd = dict(start_after=100, remove_big_after=10 ** 9, stop_after=500, densify_every=100, grad_thresh=grad_thresh, num_to_split_into=2,
+              removal_opacity_threshold=removal, final_removal_opacity_threshold=removal, reset_opacities=False, reset_opacities_every=250)
+    params, variables = SE.densify(params, variables, opt, 200, dd)
+    n = params["means3D"].shape[0]
+    if expect == "prune_only":
+        keep = op >= removal
+        assert n == int(keep.sum()) and 0 < n < P
+        for k in KEYS:
+            assert torch.equal(params[k].detach(), before[k][keep]), k
+    elif expect == "empty_map":
+        assert n == 0 and all(params[k].shape[0] == 0 for k in KEYS) and variables["denom"].shape == (0,)
+    else:
+        assert n == P
+        for k in KEYS:
+            assert torch.equal(params[k].detach(), before[k]), k
+    assert variables["denom"].shape == (n,) and not bool(variables["means2D_gradient_accum"].any())
+    assert params["cam_trans"].shape == (1, 3, 5)
+    (params["means3D"].sum() + params["semantic"].sum()).backward()
+    opt.step()
