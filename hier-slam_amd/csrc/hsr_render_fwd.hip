@@ -111,10 +111,19 @@ __device__ __forceinline__ void quad_fma_words(float (&s)[16], const float (&x)[
     }
 }
 
+#ifndef HSR_FWD_BATCH_48
+#define HSR_FWD_BATCH_48 152     // 33..48 channels, four workgroups per CU (4 x 40 720 B of LDS)
+#endif
+#ifndef HSR_FWD_BATCH_WIDE
+#define HSR_FWD_BATCH_WIDE 144   // 81..112 channels (PF), two workgroups per CU (the 128-channel instantiation fits 128)
+#endif
 template <int KC>
 struct FwdCfg {
     // LDS per staged splat: 32 (x, y, A, B, C, opacity, r, g) + 4 * round4(KC + 2) (features, b, depth)
-    static constexpr int BATCH = KC <= 32 ? 256 : (KC <= 80 ? 128 : 64);
+    // 33..80 channels: as many entries per batch as three (four up to 48 channels) workgroups per CU leave room for — every batch costs
+    // two workgroup barriers, a list publication and a round of exposed latency (128 -> 144 entries, 152 up to 48 channels: K = 48
+    // 0.278 -> 0.263 ms, K = 64 0.366 -> 0.354, K = 74 0.364 -> 0.351, 1920x1080 / 2M / K = 74 1.260 -> 1.215); the 80-channel instantiation fits 136
+    static constexpr int BATCH = KC <= 32 ? 256 : (KC <= 48 ? HSR_FWD_BATCH_48 : (KC <= 64 ? 144 : (KC == 74 ? 144 : (KC <= 80 ? 136 : 64))));
 };
 
 // KC: semantic channels handled by this launch (0 = none).  BASE: also produce colour/depth/median/
@@ -133,7 +142,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
     // SUB: 240 splats per batch keep the 16 lists + records of K = 26 under 40 KB (four workgroups per CU); K = 16 fits five (31 KB, 96
     // registers: forward 0.147 -> 0.142 ms); K = 26 with touched rows + quad-shared rows at five: 0.177 vs 0.177 ms, not taken.  (PF at K = 26 with
     // 184-splat batches and five waves per SIMD was measured too: 96 registers with 5 spills, 0.174 vs 0.165 ms — not taken.)
-    constexpr int BATCH = (SUB && KC <= 32) ? (KC > 26 ? 200 : 240) : ((PF && KC > 80) ? 128 : FwdCfg<KC>::BATCH);   // KC = 32: 200 x 176 B + lists < 40 KB; PF beyond 80 channels: two workgroups per CU, 128 x (32 + 4 KC + 8) B < 80 KB
+    constexpr int BATCH = (SUB && KC <= 32) ? (KC > 26 ? 200 : 240) : ((PF && KC > 80) ? (KC <= 112 ? HSR_FWD_BATCH_WIDE : 128) : FwdCfg<KC>::BATCH);   // KC = 32: 200 x 176 B + lists < 40 KB; PF beyond 80 channels: two workgroups per CU, 128 x (32 + 4 KC + 8) B < 80 KB
     // per staged splat: a 32-byte record { x, y, A, B | C, opacity, r, g } (pre-scaled conic, see hsr_tile_common.h) — all the
     // alpha test needs, in two 16-byte reads at one address — and a feature row { s0 .. s(KC-1), b, depth } whose 16-byte reads
     // pair up with the packed FMAs (blue and depth ride in the row's padding at K = 26): one LDS read and one address

@@ -621,8 +621,9 @@ def test_non_finite_gaussians_are_culled_and_harm_nothing():
         gp, gc = lp[n].grad, lc[n].grad
         assert torch.isfinite(gp).all(), n
         assert not bool(gp[badd].any()), n
-        # the survivors' sums are accumulated with float atomics in whatever order the tiles finish: same values up to that noise
-        assert float((gp[~badd] - gc).abs().max()) <= 1e-5 * max(1.0, float(gc.abs().max())), n
+        # the survivors' sums are accumulated with float atomics in whatever order the tiles finish, and the anisotropic scene's scale /
+        # rotation chain amplifies that noise (two runs of one scene differ by ~2e-5 of the maximum): same values up to 2e-4
+        assert float((gp[~badd] - gc).abs().max()) <= 2e-4 * max(1.0, float(gc.abs().max())), n
 
 
 def test_no_device_or_host_memory_growth_over_many_steps():
