@@ -911,8 +911,21 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
         const uint32_t ty = (uint32_t)(tile / gx), tx = (uint32_t)(tile % gx);
         const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
         real* dsem = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
-        for (int tyy = 0; tyy < BLOCK_Y; tyy++)
-            for (int txx = 0; txx < BLOCK_X; txx++) {
+        /* fp32 model: the pixels of a tile in a seeded random order too — the reference's 256 threads of a block add with atomicAdd in
+         * whatever order the hardware serialises them (backward.cu:616-663), not in raster order, which would add neighbouring (similar)
+         * terms one after the other and understate the spread */
+        int pix_order[BLOCK_X * BLOCK_Y];
+        for (int i = 0; i < BLOCK_X * BLOCK_Y; i++) pix_order[i] = i;
+        if (fp32_acc) {
+            uint64_t st = 0xA0761D6478BD642Full ^ ((uint64_t)g_accum_seed * 0xE7037ED1A0B428DBull + (uint64_t)tile * 0x8EBC6AF09C88C6E3ull + 1ull);
+            for (int i = BLOCK_X * BLOCK_Y; i > 1; i--) {
+                st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+                const int j = (int)(st % (uint64_t)i);
+                const int t_ = pix_order[i - 1]; pix_order[i - 1] = pix_order[j]; pix_order[j] = t_;
+            }
+        }
+        for (int pi = 0; pi < BLOCK_X * BLOCK_Y; pi++) {
+                const int tyy = pix_order[pi] / BLOCK_X, txx = pix_order[pi] % BLOCK_X;
                 uint32_t px = tx * BLOCK_X + txx, py = ty * BLOCK_Y + tyy;
                 if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
                 size_t pix_id = (size_t)W * py + px;

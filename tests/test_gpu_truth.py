@@ -22,8 +22,12 @@ from test_gpu_fuzz import _cases
 
 pytestmark = pytest.mark.gpu
 
+# (fuzz seed, case name[, number of cases generated]) — every case a longer fuzz run ever flagged
 FUZZ_OUTLIERS = [(9, "537_88x79_P2500_K53_aniso_x3"), (9, "565_170x112_P2500_K74_aniso_x3"), (9, "798_69x39_P300_K1_aniso_x1"),
-                 (5, "106_175x18_P2500_K53_aniso_x3"), (5, "677_168x126_P2500_K3_aniso_x1")]
+                 (5, "106_175x18_P2500_K53_aniso_x3"), (5, "677_168x126_P2500_K3_aniso_x1"),
+                 # late round 3, 3 000 cases: dL_drotations of one 20:1 needle that covers all 56 tiles: HIP 1.4e-4 of max from the truth in
+                 # every run, the fp32 oracle 0.3e-4, eight fp32 arrival orders of the reference's formulation up to 1.0e-4
+                 (4242, "2571_101x121_P2500_K16_aniso_x3", 3000)]
 REPORTS = {}
 
 
@@ -34,13 +38,13 @@ def _scene(name, seed, n=1000):
     return cam, sc, up, semantic, variant
 
 
-SEEDS = (0, 1, 2, 3, 4, 5)   # fp32-atomics model: six arrival orders of the per-Gaussian sums (tests/harness.truth_report)
+SEEDS = (0, 1, 2, 3, 4, 5, 6, 7)   # fp32-atomics model: eight arrival orders of the per-Gaussian sums (tests/harness.truth_report)
 
 
 def _check(name, rep):
     """HIP meets the 1e-4 bar against the truth — tensor-wide and element-wise — except where fp32 arithmetic itself cannot: there
     HIP may be at most twice as far from the truth as the farther of (the fp32 oracle, the fp32-atomics model of the reference's own
-    accumulation over six arrival orders), plus the rounding floor.  A defect in a kernel shows as HIP alone being far."""
+    accumulation over eight arrival orders), plus the rounding floor.  A defect in a kernel shows as HIP alone being far."""
     REPORTS[name] = rep
     assert rep["lists_equal"]
     for tname, t in rep["tensors"].items():
@@ -51,9 +55,10 @@ def _check(name, rep):
             assert h[key] <= max(1e-4, 2.0 * floor + 2e-5), (name, tname, key, h, o, m)
 
 
-@pytest.mark.parametrize("seed,name", FUZZ_OUTLIERS, ids=[n for _, n in FUZZ_OUTLIERS])
-def test_fuzz_outliers_against_the_truth(seed, name):
-    cam, sc, up, semantic, variant = _scene(name, seed)
+@pytest.mark.parametrize("case", FUZZ_OUTLIERS, ids=[c[1] for c in FUZZ_OUTLIERS])
+def test_fuzz_outliers_against_the_truth(case):
+    seed, name = case[0], case[1]
+    cam, sc, up, semantic, variant = _scene(name, seed, *case[2:])
     _check(name, truth_report(cam, sc, up, semantic=semantic, variant=variant, atomics_seeds=SEEDS))
 
 
