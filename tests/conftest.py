@@ -59,8 +59,8 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
                 len(test_gpu_parity.TIE_BOUNDED), ", ".join(sorted(set(test_gpu_parity.TIE_BOUNDED)))))
         if test_gpu_parity.CONDITIONED:
             c = test_gpu_parity.CONDITIONED
-            tr.write_line("gradient comparisons settled against the TRUTH build (HIP within 2x the fp32 noise floor: oracle32 + four fp32-atomics "
-                          "orders): %d; worst element-wise HIP-vs-truth %.2e at a floor of %.2e (%s)" % (
+            tr.write_line("gradient comparisons settled against the TRUTH build (HIP within 2x the fp32 noise floor: oracle32, eight fp32-atomics "
+                          "orders, one-upstream-gradient-at-a-time runs): %d; worst element-wise HIP-vs-truth %.2e at a floor of %.2e (%s)" % (
                               len(c), max(x[1] for x in c), max(x[2] for x in c), ", ".join(sorted(set(x[0] for x in c)))))
     except Exception:
         pass
