@@ -1026,15 +1026,21 @@ void launch_subw_pass(const RenderBwdArgs& a, int c0, int ns, dim3 grid, hipStre
     // bf16 matrix cores on the exact three-way split where they paid (tools/wide_mma_ab.sh, 500k Gaussians, bwd_render ms, fp32 -> split):
     // 4 column groups 0.495 -> 0.486, 5 groups 0.606 -> 0.573 (1920x1080, 2M: 2.168 -> 2.058); 3 groups lose (0.407 -> 0.419: 24 B
     // registers per group push the kernel from 3 waves per SIMD to 2); 2 groups (K <= 27) tie even at 3 waves; 6 and 7 groups do not fit.
-    static const char* e_mma = getenv("HSR_BWD_WIDE_MMA");   // kernel-family selector (parity-tested): "f32" = fp32 matrix instructions
+#ifdef HSR_ABLATE
+    static const char* e_mma = getenv("HSR_BWD_WIDE_MMA");   // A/B selector, ablate build only (parity-tested there): "f32" = fp32 matrix instructions
     const bool bf = !(e_mma && !strcmp(e_mma, "f32"));
+#else
+    constexpr bool bf = true;
+#endif
     if (groups <= 1) render_bwd_subw_kernel<1, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
     else if (groups == 2) render_bwd_subw_kernel<2, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
     else if (groups == 3) render_bwd_subw_kernel<3, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
     else if (groups == 4 && bf) render_bwd_subw_kernel<4, BASE, 224, true><<<grid, block, 0, stream>>>(a, c0, ns);
-    else if (groups == 4) render_bwd_subw_kernel<4, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
     else if (groups == 5 && bf) render_bwd_subw_kernel<5, BASE, 224, true><<<grid, block, 0, stream>>>(a, c0, ns);
+#ifdef HSR_ABLATE
+    else if (groups == 4) render_bwd_subw_kernel<4, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
     else if (groups == 5) render_bwd_subw_kernel<5, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
+#endif
     else if (groups == 6) render_bwd_subw_kernel<6, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
     else render_bwd_subw_kernel<7, BASE, 224, false><<<grid, block, 0, stream>>>(a, c0, ns);
 }

@@ -672,9 +672,14 @@ int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
         case 16: render_fwd_kernel<16, true, false, true, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;   // ScanNet tree
         case 26: render_fwd_kernel<26, true, false, true, true><<<grid, block, 0, stream>>>(a, 0); return HSR_OK;   // Replica tree
         case 74: {   // ScanNet large tree
-            static const bool no_pf = getenv("HSR_FWD_PF") && !strcmp(getenv("HSR_FWD_PF"), "0");   // A/B selector (parity-tested)
-            if (no_pf) render_fwd_kernel<74, true, false, true, true><<<grid, block, 0, stream>>>(a, 0);
-            else render_fwd_kernel<74, true, false, true, true, true><<<grid, block, 0, stream>>>(a, 0);
+#ifdef HSR_ABLATE
+            static const bool no_pf = getenv("HSR_FWD_PF") && !strcmp(getenv("HSR_FWD_PF"), "0");   // A/B selector, ablate build only: rows parked in registers
+            if (no_pf) {
+                render_fwd_kernel<74, true, false, true, true><<<grid, block, 0, stream>>>(a, 0);
+                return HSR_OK;
+            }
+#endif
+            render_fwd_kernel<74, true, false, true, true, true><<<grid, block, 0, stream>>>(a, 0);
             return HSR_OK;
         }
         case 102:   // Replica flat label set
