@@ -1,4 +1,6 @@
 #!/bin/bash
+# (kernel-family / A-B selectors and ablation switches live in the ablate build: make -C hier-slam_amd/csrc ablate)
+export HSR_RAST_LIB=${HSR_RAST_LIB:-$PWD/hier-slam_amd/libhsr_rast_ablate.so} HSR_GLUE=ctypes
 cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "k74 or k75 or k76" 2>&1 | tail -2
 for pf in 1 0; do

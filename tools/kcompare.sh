@@ -1,4 +1,6 @@
 # forward-stage time, wide matrix-core kernel vs per-lane kernels, for several K
+# (kernel-family / A-B selectors and ablation switches live in the ablate build: make -C hier-slam_amd/csrc ablate)
+export HSR_RAST_LIB=${HSR_RAST_LIB:-$PWD/hier-slam_amd/libhsr_rast_ablate.so} HSR_GLUE=ctypes
 for k in 33 40 60 74 90 102 124; do
   for impl in wide valu; do
     if [ $impl = valu ]; then export HSR_FWD_IMPL=valu; else unset HSR_FWD_IMPL; fi

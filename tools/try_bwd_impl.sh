@@ -1,4 +1,6 @@
 # parity cases + headline bench with HSR_BWD_IMPL=$1 (usage: bash tools/try_bwd_impl.sh mom)
+# (kernel-family / A-B selectors and ablation switches live in the ablate build: make -C hier-slam_amd/csrc ablate)
+export HSR_RAST_LIB=${HSR_RAST_LIB:-$PWD/hier-slam_amd/libhsr_rast_ablate.so} HSR_GLUE=ctypes
 export HSR_BWD_IMPL=$1
 python - <<'PY'
 import sys; sys.path[:0]=['hier-slam_amd','tests']
