@@ -133,12 +133,15 @@ class GradientExchange:
       radii > 0 on a side stream while the backward runs; submit() then exchanges only the rows of the union: gather into a
       compact buffer, ONE all-reduce, scatter back.  The result equals the dense all-reduce — bit for bit with two ranks (a + b),
       up to the order of the ring's fp32 additions with more — and rows outside the union stay the zeros the backward wrote.
-      When the union covers more than `dense_above` of the rows the bucket is all-reduced whole (no gather / scatter).
+      When the union covers more than `dense_above` of the rows the bucket is all-reduced whole (no gather / scatter) — and after
+      `probe_after` such steps in a row the mask itself (a P-byte all-reduce, a nonzero() and the host wait for both) is only
+      exchanged every `probe_every`-th step until a probe finds the union sparse again.  Every rank takes that decision from the
+      same all-reduced masks, so all ranks skip and probe in the same steps.
     * **Pipelined** like PipelinedAllReduce: `depth` buckets, a bucket is waited for only when it is handed out again, drain()
       at the end; reduced(step) gives the summed gradients of a step as views.
     """
 
-    def __init__(self, params, device, depth=2, group=None, average=False, sparse=True, dense_above=0.75):
+    def __init__(self, params, device, depth=2, group=None, average=False, sparse=True, dense_above=0.75, probe_after=3, probe_every=16):
         if not isinstance(params, dict):
             raise TypeError("params: {gradient-sink name: leaf tensor}")
         self.names = list(params)
@@ -155,10 +158,12 @@ class GradientExchange:
         self.group, self.average, self.sparse, self.dense_above = group, average, bool(sparse), float(dense_above)
         self.step, self.cur = 0, None
         self._mask = None          # (pending work | None, uint8 [P] union mask, event | None)
+        self.probe_after, self.probe_every = int(probe_after), int(probe_every)
+        self._dense_run = 0        # consecutive steps whose union was dense (or that skipped the probe while in a dense run)
         self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self._handed = {}
         self._stats = dict(steps=0, zero_copy_tensors=0, copied_tensors=0, bytes_dense_equivalent=0, bytes_exchanged=0,
-                           sparse_steps=0, union_rows=0, mask_bytes=0)
+                           sparse_steps=0, union_rows=0, mask_bytes=0, masks_exchanged=0)
 
     # ---- the sink ----
     def _sink(self, name, shape, dev):
@@ -189,8 +194,12 @@ class GradientExchange:
         for t in self.leaves:
             t.grad = None
         self._prev_sink = _C.set_gradient_sink(self._sink)
-        if radii is not None and self.sparse and self._world() > 1:
+        if radii is not None and self.sparse and self._world() > 1 and self._probe_now():
             self.announce(radii)
+
+    def _probe_now(self):
+        """exchange the visibility mask in this step?  Always, until `probe_after` dense steps in a row; then every `probe_every`-th"""
+        return self._dense_run < self.probe_after or (self._dense_run - self.probe_after) % self.probe_every == 0
 
     def announce(self, radii):
         """all-reduce(max) of the byte mask radii > 0, on a side stream beside the backward"""
@@ -204,6 +213,7 @@ class GradientExchange:
             w = dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         self._mask = (w, m)
         self._stats["mask_bytes"] += int(m.numel())
+        self._stats["masks_exchanged"] += 1
 
     def submit(self, radii=None):
         """call after backward(): starts the exchange of this step's gradients; returns the bucket index"""
@@ -231,7 +241,7 @@ class GradientExchange:
             return b
         idx = None
         if self.sparse:
-            if self._mask is None and radii is not None:
+            if self._mask is None and radii is not None and self._probe_now():
                 self.announce(radii)
             if self._mask is not None:
                 w, m = self._mask
@@ -246,6 +256,11 @@ class GradientExchange:
                     idx = m.nonzero(as_tuple=False).flatten()
                 if idx.numel() > self.dense_above * self.P:
                     idx = None
+                    self._dense_run += 1
+                else:
+                    self._dense_run = 0
+            elif self._dense_run >= self.probe_after:
+                self._dense_run += 1      # a skipped probe inside a dense run: stays dense
         if idx is None:
             self.pending[b] = bucket.all_reduce(group=self.group, average=self.average, async_op=True)
             self._stats["bytes_exchanged"] += dense_bytes

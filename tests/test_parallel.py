@@ -144,6 +144,36 @@ def _exchange_checks(rank, world):
     assert st["zero_copy_tensors"] == 12 and st["copied_tensors"] == 0
     assert st["sparse_steps"] == 3 and st["bytes_exchanged"] < st["bytes_dense_equivalent"]
     assert abs(st["union_fraction"] - (160 + 80 + 0) / (3 * 200)) < 1e-9
+    # a run of dense steps: after `probe_after` of them the mask is only exchanged every `probe_every`-th step (same steps on every rank)
+    ex2 = GradientExchange(leaves, "cpu", depth=2, sparse=True, dense_above=0.5, probe_after=2, probe_every=3)
+    full = torch.full((P,), 3, dtype=torch.int32)
+    for step in range(7):
+        grads = [torch.randn(t.shape, generator=gen) for t in leaves.values()]
+        ex2.begin_step(full)
+        _ToyRender.apply(*leaves.values(), *grads).backward()
+        ex2.submit()
+        for r, g in zip(ref_leaves, grads):
+            r.grad = g.clone()
+        allreduce_gradients(ref_leaves)
+        for v, r in zip(ex2.reduced(step), ref_leaves):
+            assert torch.equal(v, r.grad), step
+    st2 = ex2.stats()
+    assert st2["masks_exchanged"] == 4 and st2["sparse_steps"] == 0, st2      # probes before steps 0, 1, 2 and 5
+    half = torch.zeros(P, dtype=torch.int32); half[:40] = 3                    # the run ends when a probe finds the union sparse again
+    for step in range(7, 12):
+        grads = [torch.randn(t.shape, generator=gen) for t in leaves.values()]
+        for g in grads:
+            g[40:] = 0.0
+        ex2.begin_step(half)
+        _ToyRender.apply(*leaves.values(), *grads).backward()
+        ex2.submit()
+        for r, g in zip(ref_leaves, grads):
+            r.grad = g.clone()
+        allreduce_gradients(ref_leaves)
+        for v, r in zip(ex2.reduced(step), ref_leaves):
+            assert torch.equal(v, r.grad), step
+    ex2.drain()
+    assert ex2.stats()["sparse_steps"] >= 3, ex2.stats()                       # probed at the latest three steps into the sparse phase
     # a gradient that did not come through the sink (another producer) is packed, not lost
     ex.begin_step(None)
     for t in leaves.values():
