@@ -28,7 +28,9 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "GaussianRaste
 def set_async_forward(on):
     """Opt-in: a forward that a backward will follow returns before the device has counted num_rendered (the reference — and the
     default here — waits for that 4-byte read-back in every frame).  See diff_gaussian_rasterization/_C.py for the one condition
-    under which this raises (num_rendered more than doubling between two frames of the same size).  Returns the previous setting."""
+    under which this raises (num_rendered more than doubling between two frames of the same size).  Errors the device finds during such a
+    forward — that overflow, a `prefiltered` violation — surface when the count is resolved (in the backward), not at the forward call.
+    Returns the previous setting."""
     return _C.set_async_forward(on)
 
 
