@@ -12,6 +12,7 @@ include/hsr_rasterizer.h (ctypes; no torch types cross the boundary).  There is 
 shared library is missing or the tensors are not on a HIP device, these functions raise.
 """
 import ctypes as C
+import itertools
 import os
 
 import torch
@@ -331,21 +332,41 @@ def _require_gpu(means3D):
                            "this build has no CPU path" % means3D.device)
 
 
+_live_growers = {}          # key -> [tensor, device] of the hsr_buffers of forward calls in flight (keys ride in hsr_buffer.user)
+_grower_keys = itertools.count(1)
+
+
+def _grow_dispatch(nbytes, user):
+    try:
+        h = _live_growers[int(user)]
+        h[0] = torch.empty(int(nbytes), dtype=torch.uint8, device=h[1])
+        return h[0].data_ptr()
+    except Exception:  # report failure through the C return code
+        return None
+
+
+# ONE callback object for the whole module: every ctypes callback is a reference cycle in itself (function pointer <-> thunk), so a
+# callback per call that closes over its tensor kept the three state buffers of every forward alive until the cyclic collector ran
+# (measured through this glue: one to two iterations' worth of device memory pending at any time)
+_GROW_CB = _GROW_FN(_grow_dispatch)
+
+
 class _Grower:
-    """Adapts a torch uint8 tensor to hsr_buffer: pre-sized allocation + grow callback."""
+    """Adapts a torch uint8 tensor to hsr_buffer: pre-sized allocation + grow callback (the module's one callback, which finds this
+    buffer through the key in hsr_buffer.user); close() when the library call has returned."""
 
     def __init__(self, nbytes, dev):
-        self.dev = dev
-        self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        self.cb = _GROW_FN(self._grow)
-        self.buf = _HsrBuffer(self.t.data_ptr() if nbytes else None, int(nbytes), C.cast(self.cb, C.c_void_p), None)
+        self._key = next(_grower_keys)
+        self._h = [torch.empty(int(nbytes), dtype=torch.uint8, device=dev), dev]
+        _live_growers[self._key] = self._h
+        self.buf = _HsrBuffer(self._h[0].data_ptr() if nbytes else None, int(nbytes), C.cast(_GROW_CB, C.c_void_p), self._key)
 
-    def _grow(self, nbytes, _user):
-        try:
-            self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
-            return self.t.data_ptr()
-        except Exception:  # report failure through the C return code
-            return None
+    @property
+    def t(self):
+        return self._h[0]
+
+    def close(self):
+        _live_growers.pop(self._key, None)
 
 
 def _forward_common(semantic, background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
@@ -389,6 +410,10 @@ def _forward_common(semantic, background, means3D, colors, semantics, opacity, s
         out_opacity = torch.empty((1, H, W), **fopt)
         out_aux = torch.empty((K if semantic else 1, H, W), **fopt)  # semantic map or mask
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+        tens = [_prep(x, dev) for x in (background, means3D, sh, colors, semantics if semantic else None, opacity, scales,
+                                        rotations, cov3D_precomp, viewmatrix, projmatrix, campos)]
+        bg_, m3_, sh_, col_, sem_, op_, sc_, rot_, cov_, vm_, pm_, cp_ = tens
         if P == 0:
             geom = _Grower(0, dev); binning = _Grower(0, dev); img = _Grower(0, dev)
         else:
@@ -397,28 +422,28 @@ def _forward_common(semantic, background, means3D, colors, semantics, opacity, s
             hint = _binning_hint.get((dev.index, P, W, H), 4 * P)
             # a call that runs ahead cannot grow the buffer afterwards: twice the last count instead of a quarter more
             binning = _Grower(_lib.hsr_required_binning_bytes(int(hint * (2.0 if run_ahead else 1.25)) + 1024), dev)
-        M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
-        tens = [_prep(x, dev) for x in (background, means3D, sh, colors, semantics if semantic else None, opacity, scales,
-                                        rotations, cov3D_precomp, viewmatrix, projmatrix, campos)]
-        bg_, m3_, sh_, col_, sem_, op_, sc_, rot_, cov_, vm_, pm_, cp_ = tens
         ticket = None
         if run_ahead and P:
             ticket = _Ticket()
             _lib.hsr_forward_arm_async(C.byref(ticket))
-        if semantic:
-            rc = _lib.hsr_forward_semantic(
-                C.byref(geom.buf), C.byref(binning.buf), C.byref(img.buf), P, int(degree), M, K, _ptr(bg_), W, H, _ptr(m3_),
-                _ptr(sh_), _ptr(col_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(cov_),
-                _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-                _ptr(out_color), _ptr(out_aux), _ptr(out_depth), _ptr(out_median), _ptr(out_opacity), _ptr(radii),
-                int(bool(debug)), stream)
-        else:
-            rc = _lib.hsr_forward(
-                C.byref(geom.buf), C.byref(binning.buf), C.byref(img.buf), P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_),
-                _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(cov_),
-                _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-                _ptr(out_color), _ptr(out_depth), _ptr(out_median), _ptr(out_opacity), _ptr(out_aux), _ptr(radii),
-                int(bool(debug)), stream)
+        try:
+            if semantic:
+                rc = _lib.hsr_forward_semantic(
+                    C.byref(geom.buf), C.byref(binning.buf), C.byref(img.buf), P, int(degree), M, K, _ptr(bg_), W, H, _ptr(m3_),
+                    _ptr(sh_), _ptr(col_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(cov_),
+                    _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                    _ptr(out_color), _ptr(out_aux), _ptr(out_depth), _ptr(out_median), _ptr(out_opacity), _ptr(radii),
+                    int(bool(debug)), stream)
+            else:
+                rc = _lib.hsr_forward(
+                    C.byref(geom.buf), C.byref(binning.buf), C.byref(img.buf), P, int(degree), M, _ptr(bg_), W, H, _ptr(m3_),
+                    _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(cov_),
+                    _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                    _ptr(out_color), _ptr(out_depth), _ptr(out_median), _ptr(out_opacity), _ptr(out_aux), _ptr(radii),
+                    int(bool(debug)), stream)
+        finally:
+            for g_ in (geom, binning, img):
+                g_.close()
         if rc == HSR_PENDING and ticket is not None:
             return LazyRendered(ticket, key, stream), out_color, out_aux, out_depth, out_median, out_opacity, radii, geom.t, binning.t, img.t
         if rc < 0:

@@ -642,9 +642,9 @@ def test_non_finite_gaussians_are_culled_and_harm_nothing():
 
 
 def test_no_device_or_host_memory_growth_over_many_steps():
-    """600 forward+backward steps (blocking and non-blocking forward, stage timers on for a third of them): device memory allocated by
-    torch returns to where it was and the process's resident set stays put — no per-call leak in the glue, the library's event pool,
-    the host-mapped counters or the ticket ring."""
+    """Two rounds of 3 x 100 forward+backward steps (blocking forward, non-blocking forward, stage timers on): the first round brings every
+    path's buffers and caches into being, over the second one device memory allocated through torch and the process's resident set stay
+    put — no per-call leak in the glue, the library's event pool, the host-mapped counters or the ticket ring."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _C
     dev = torch.device("cuda:0")
@@ -660,24 +660,26 @@ def test_no_device_or_host_memory_growth_over_many_steps():
         leaf, outs = _render_sem(cam, sc, dev)
         color, radii, sem, depth, median, opac = outs
         ((color * upd["color"]).sum() + (sem * upd["semantic"]).sum() + (depth * upd["depth"]).sum()).backward()
-    for _ in range(30):
-        step()
+
+    def one_round():
+        for phase in range(3):
+            prev = dgr.set_async_forward(phase == 1)
+            if phase == 2:
+                _C._lib.hsr_profile_enable(1)
+            try:
+                for _ in range(100):
+                    step()
+                torch.cuda.synchronize()
+            finally:
+                dgr.set_async_forward(prev)
+                if phase == 2:
+                    _C._lib.hsr_profile_read(None, 1)
+                    _C._lib.hsr_profile_enable(0)
+    one_round()
     torch.cuda.synchronize()
     mem0, rss0 = torch.cuda.memory_allocated(dev), rss_mb()
-    for phase in range(3):
-        prev = dgr.set_async_forward(phase == 1)
-        if phase == 2:
-            _C._lib.hsr_profile_enable(1)
-        try:
-            for _ in range(200):
-                step()
-            torch.cuda.synchronize()
-        finally:
-            dgr.set_async_forward(prev)
-            if phase == 2:
-                _C._lib.hsr_profile_read(None, 1)
-                _C._lib.hsr_profile_enable(0)
-    leaf = outs = None
+    one_round()
+    one_round()
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated(dev) <= mem0 + (1 << 20), (torch.cuda.memory_allocated(dev), mem0)
     assert rss_mb() - rss0 < 64.0, (rss_mb(), rss0)
