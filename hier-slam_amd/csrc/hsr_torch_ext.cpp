@@ -127,6 +127,11 @@ forward_common(bool semantic, const OptT& background, const at::Tensor& means3D,
     hsr_ticket tk;
     if (run_ahead && P) hsr_forward_arm_async(&tk);
     int rc;
+    {
+    // the call waits for the device's num_rendered (up to a whole backward's duration when the stream is busy): other Python threads —
+    // a second renderer, autograd's own Python-level backward of another graph — run meanwhile (the ctypes glue releases the GIL for
+    // every foreign call by itself); nothing below touches a Python object, the grow callbacks allocate through ATen
+    py::gil_scoped_release nogil;
     if (semantic)
         rc = hsr_forward_semantic(&gb, &bb, &ib, (int)P, (int)degree, (int)M, (int)K, ptr(bg_), (int)W, (int)H, ptr(m3_), ptr(sh_),
                                   ptr(col_), ptr(sem_), ptr(op_), ptr(sc_), (float)scale_modifier, ptr(rot_), ptr(cov_), ptr(vm_),
@@ -138,6 +143,7 @@ forward_common(bool semantic, const OptT& background, const at::Tensor& means3D,
                          ptr(sc_), (float)scale_modifier, ptr(rot_), ptr(cov_), ptr(vm_), ptr(pm_), ptr(cp_), (float)tan_fovx,
                          (float)tan_fovy, prefiltered ? 1 : 0, ptr(out_color), ptr(out_depth), ptr(out_median), ptr(out_opacity),
                          ptr(out_aux), ptr<int>(radii), debug ? 1 : 0, reinterpret_cast<void*>(stream));
+    }
     if (rc == HSR_PENDING)
         return std::make_tuple((int64_t)rc, out_color, out_aux, out_depth, out_median, out_opacity, radii, geom, binning, img,
                                py::bytes(reinterpret_cast<const char*>(&tk), sizeof(tk)));
@@ -156,7 +162,11 @@ std::tuple<int64_t, int64_t, std::string> forward_end(const py::bytes& ticket, b
     TORCH_CHECK(raw.size() == sizeof(hsr_ticket), "forward_end: not a ticket");
     hsr_ticket tk;
     memcpy(&tk, raw.data(), sizeof(tk));
-    const int rc = hsr_forward_end(&tk, block ? 1 : 0, reinterpret_cast<void*>(stream));
+    int rc;
+    {
+        py::gil_scoped_release nogil;   // may wait for the device
+        rc = hsr_forward_end(&tk, block ? 1 : 0, reinterpret_cast<void*>(stream));
+    }
     return std::make_tuple((int64_t)rc, (int64_t)tk.rendered, std::string(rc < 0 && rc != HSR_PENDING ? hsr_last_error() : ""));
 }
 
@@ -209,6 +219,8 @@ backward_common(bool semantic, const OptT& background, const at::Tensor& means3D
         const at::Tensor radii_ = prep(radii, dev, at::kInt);
         if (nscratch) scratch = at::empty({(int64_t)nscratch}, fopt.dtype(at::kByte));
         int rc;
+        {
+        py::gil_scoped_release nogil;
         if (semantic)
             rc = hsr_backward_semantic((int)P, (int)degree, (int)M, (int)K, (int)R, ptr(bg_), (int)W, (int)H, ptr(m3_), ptr(sh_), ptr(col_),
                                        ptr(sem_), ptr(sc_), (float)scale_modifier, ptr(rot_), ptr(cov_), ptr(vm_), ptr(pm_), ptr(cp_),
@@ -224,6 +236,7 @@ backward_common(bool semantic, const OptT& background, const at::Tensor& means3D
                               ptr(gdep), ptr(gmed), ptr(gop), ptr(dL_dmeans2D), ptr(dL_dconic), ptr(dL_dopacity), ptr(dL_dcolors),
                               ptr(dL_ddepths), ptr(dL_dmeans3D), ptr(dL_dcov3D), ptr(dL_dsh), ptr(dL_dscales), ptr(dL_drotations),
                               ptr<char>(scratch), nscratch, debug ? 1 : 0, reinterpret_cast<void*>(stream));
+        }
         if (rc < 0) fail(rc, semantic ? "rasterize_gaussians_backward_semantic" : "rasterize_gaussians_backward");
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
