@@ -719,3 +719,14 @@ def test_two_host_threads_render_concurrently():
             assert torch.equal(a, b)
         assert torch.equal(ref[1], got[1])
         _same_up_to_atomics_order(ref[2], got[2])
+
+
+@pytest.mark.parametrize("mod", [0.6, 1.7])
+def test_scale_modifier_other_than_one(mod):
+    """raster_settings.scale_modifier multiplies every scale before the covariance (forward.cu:118-124) and its gradient (backward.cu:
+    295-300); Hier-SLAM always passes 1.0 (utils/recon_helpers.py:20), the API allows anything"""
+    cam, sc, up = scenes.build(150, 90, 2000, 11, seed=31, kind="aniso", scale_mult=2.0)
+    cam = dict(cam, scale_modifier=float(mod))
+    _compare(cam, sc, up, True, "sr", None)
+    cam2, sc2, up2 = scenes.build(96, 80, 1200, 0, seed=32, kind="aniso", scale_mult=2.0)
+    _compare(dict(cam2, scale_modifier=float(mod)), sc2, up2, False, "sr", None)
