@@ -730,3 +730,20 @@ def test_scale_modifier_other_than_one(mod):
     _compare(cam, sc, up, True, "sr", None)
     cam2, sc2, up2 = scenes.build(96, 80, 1200, 0, seed=32, kind="aniso", scale_mult=2.0)
     _compare(dict(cam2, scale_modifier=float(mod)), sc2, up2, False, "sr", None)
+
+
+def test_off_centre_principal_point_and_unequal_focal_lengths():
+    """ScanNet-like intrinsics: fx != fy and (cx, cy) away from the image centre — tanfovx / tanfovy then differ and the projection
+    matrix is asymmetric (utils/recon_helpers.py:4-28 builds both from the same K); the scenes of the other cases all use centred
+    Replica intrinsics"""
+    import numpy as np
+    from hsr_utils.camera import setup_camera_tensors
+    from hsr_utils.synthetic import make_scene, make_upstream_grads
+    W, H, P, K = 160, 120, 2500, 16
+    k = np.array([[155.0, 0.0, 0.41 * W], [0.0, 171.0, 0.57 * H], [0.0, 0.0, 1.0]])
+    w2c = scenes.tilted_w2c(0.15, (0.05, 0.1, 0.1))
+    cam = setup_camera_tensors(W, H, k, w2c)
+    assert abs(cam["tanfovx"] * 155.0 / W - cam["tanfovy"] * 171.0 / H) < 1e-6 and cam["tanfovx"] / cam["tanfovy"] != W / H
+    sc = make_scene(P, W, H, K, k, seed=12, kind="aniso", scale_mult=2.0, w2c=w2c)
+    up = {n: v * float(W * H) for n, v in make_upstream_grads(W, H, K, seed=2).items()}
+    _compare(cam, sc, up, True, "sr", None)
