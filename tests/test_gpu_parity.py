@@ -747,3 +747,52 @@ def test_off_centre_principal_point_and_unequal_focal_lengths():
     sc = make_scene(P, W, H, K, k, seed=12, kind="aniso", scale_mult=2.0, w2c=w2c)
     up = {n: v * float(W * H) for n, v in make_upstream_grads(W, H, K, seed=2).items()}
     _compare(cam, sc, up, True, "sr", None)
+
+
+@pytest.mark.parametrize("glue", ["compiled", "ctypes"])
+def test_non_contiguous_inputs_and_partial_requires_grad(glue):
+    """inputs that are strided views (a column slice of a wider table, a transposed buffer) render like their contiguous copies, bit
+    for bit; gradients come back for exactly the inputs that asked for one"""
+    import subprocess
+    import sys
+    code = r'''
+import sys; sys.path[:0]=['hier-slam_amd','tests']
+import torch, scenes
+from diff_gaussian_rasterization import GaussianRasterizer_semantic
+from harness import _cam_to
+dev = torch.device("cuda:0")
+cam, sc, up = scenes.build(150, 90, 2000, 11, seed=41, kind="aniso", scale_mult=2.0)
+P = sc["means3D"].shape[0]
+def render(inputs):
+    return GaussianRasterizer_semantic(_cam_to(cam, dev))(means2D=torch.zeros(P, 3, device=dev, requires_grad=True), **inputs)
+names = ("means3D", "opacities", "colors_precomp", "scales", "rotations", "semantics_precomp")
+plain = {n: sc[n].to(dev).clone().requires_grad_(n in ("means3D", "colors_precomp")) for n in names}
+strided = {}
+for n in names:
+    t = sc[n].to(dev)
+    wide = torch.zeros(P, t.shape[1] + 3, device=dev); wide[:, 1:1 + t.shape[1]] = t
+    v = wide[:, 1:1 + t.shape[1]] if n != "rotations" else t.t().contiguous().t()      # column slice / transposed storage
+    assert not v.is_contiguous()
+    strided[n] = v.detach().requires_grad_(n in ("means3D", "colors_precomp"))
+oa, ob = render(plain), render(strided)
+for a, b in zip(oa, ob):
+    assert torch.equal(a, b)
+upd = {n: v.to(dev) for n, v in up.items()}
+for outs in (oa, ob):
+    color, radii, sem, depth, median, opac = outs
+    ((color * upd["color"]).sum() + (sem * upd["semantic"]).sum() + (depth * upd["depth"]).sum()).backward()
+for n in names:
+    if n in ("means3D", "colors_precomp"):
+        ga, gb = plain[n].grad, strided[n].grad
+        assert ga is not None and gb is not None and gb.shape == ga.shape
+        assert float((ga - gb).abs().max()) <= (1e-3 if n == "means3D" else 2e-5) * max(1.0, float(ga.abs().max())), n
+    else:
+        assert plain[n].grad is None and strided[n].grad is None, n
+print("ok")
+'''
+    env = dict(os.environ)
+    if glue == "ctypes":
+        env["HSR_GLUE"] = "ctypes"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
