@@ -796,3 +796,27 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_backward_twice_through_a_retained_graph():
+    """loss.backward(retain_graph=True) twice: the saved state buffers serve both passes (the reference's do too) and the leaves'
+    gradients accumulate to exactly twice one pass's (up to the atomics' order); also with the non-blocking forward, whose count is
+    resolved by the first pass and reused by the second"""
+    import diff_gaussian_rasterization as dgr
+    dev = torch.device("cuda:0")
+    cam, sc, up = scenes.build(150, 90, 2000, 11, seed=43, kind="slam")
+    upd = {n: v.to(dev) for n, v in up.items()}
+    once = _fwd_bwd(cam, sc, up, dev)[2]
+    for asyn in (False, True):
+        prev = dgr.set_async_forward(asyn)
+        try:
+            leaf, outs = _render_sem(cam, sc, dev)
+            color, radii, sem, depth, median, opac = outs
+            loss = (color * upd["color"]).sum() + (sem * upd["semantic"]).sum() + (depth * upd["depth"]).sum() \
+                + (median * upd["median"]).sum() + (opac * upd["opacity"]).sum()
+            loss.backward(retain_graph=True)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            dgr.set_async_forward(prev)
+        _same_up_to_atomics_order({n: 2.0 * v for n, v in once.items()}, {n: leaf[n].grad for n in leaf})
