@@ -261,7 +261,7 @@ class Workload:
 
     names = ("means3D", "colors_precomp", "semantics_precomp", "opacities", "scales", "rotations")
 
-    def __init__(self, dev, W, H, P, K, kind, rank=0, world=1, device_tensors=True, behind_frac=0.0):
+    def __init__(self, dev, W, H, P, K, kind, rank=0, world=1, device_tensors=True, behind_frac=0.0, geo=False):
         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer_semantic
         from hsr_utils.camera import replica_intrinsics, setup_camera_tensors
         from hsr_utils.synthetic import make_scene, make_upstream_grads
@@ -270,19 +270,23 @@ class Workload:
         self.cam_cpu = setup_camera_tensors(W, H, kmat, perturbed_w2c(rank))
         self.sc = make_scene(P, W, H, K, kmat, seed=0, kind=kind, behind_frac=behind_frac)  # same Gaussians on every rank (replicated parameters)
         self.behind_frac = behind_frac
+        self.geo = geo
         self.up = make_upstream_grads(W, H, K, seed=1 + rank)
         self.exchange = None
         self.info = {}
         if device_tensors:
             cam = GaussianRasterizationSettings(**{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in self.cam_cpu.items()})
-            self.leaf = {n: self.sc[n].to(dev).requires_grad_(True) for n in self.names}
+            # geo: a tracking iteration (scripts/hierslam.py:1683-1860) — only the camera pose is optimised, so autograd asks for the
+            # gradient of the (transformed) means alone and the backward takes its geometry-only path
+            self.leaf = {n: self.sc[n].to(dev).requires_grad_(not geo or n == "means3D") for n in self.names}
             self.upd = [self.up[n].to(dev) for n in ("color", "semantic", "depth", "median", "opacity")]
             self.renderer = GaussianRasterizer_semantic(cam)
 
     def describe(self):
         return ("semantic fwd+bwd render, %dx%d, P=%d %s Gaussians%s, K=%d semantic channels, dense upstream grads on "
-                "colour/semantic/depth/median/opacity" % (self.W, self.H, self.P, self.kind,
-                                                          (" (%.0f %% behind the camera)" % (100 * self.behind_frac)) if self.behind_frac else "", self.K))
+                "colour/semantic/depth/median/opacity%s" % (self.W, self.H, self.P, self.kind,
+                                                            (" (%.0f %% behind the camera)" % (100 * self.behind_frac)) if self.behind_frac else "", self.K,
+                                                            "; gradients for means3D / means2D only (tracking iteration)" if self.geo else ""))
 
     def release(self):
         self.leaf = self.upd = self.renderer = None
@@ -399,6 +403,7 @@ def main():
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=680)
     ap.add_argument("--kind", default="slam", choices=["slam", "aniso"])
+    ap.add_argument("--geo", action="store_true", help="tracking iteration: gradients for means3D / means2D only (geometry-only backward)")
     ap.add_argument("--behind-frac", type=float, default=0.0, help="fraction of the Gaussians placed behind the camera (culled): a camera that sees part of the map")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (also skips the parity block)")
@@ -459,7 +464,7 @@ def main():
     from hsr_utils.parallel import GradientExchange
 
     W, H, K, P = args.width, args.height, args.K, args.P
-    wl = Workload(dev, W, H, P, K, args.kind, rank, world, behind_frac=args.behind_frac)
+    wl = Workload(dev, W, H, P, K, args.kind, rank, world, behind_frac=args.behind_frac, geo=args.geo)
     exch = None
     if world > 1:
         # N > 1: the one exchange step of the sharded path.  The leaves' .grad tensors are VIEWS of the exchange

@@ -628,6 +628,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
 #else
     const bool use_rows = false;
 #endif
+    int glayout = 0;   // set below once the accumulation mode is known
     int gstride = hsr_grow_stride(K);
     const bool use_packed = !use_rows && backward_mode() != 2 && in.scratch &&
                             in.scratch_bytes >= (size_t)P * gstride * sizeof(float) + 256;
@@ -656,6 +657,10 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
 #endif
     if (use_packed) {
         if (geo) gstride = 16;   // one 64-byte line per Gaussian: columns 0..6
+        else {
+            glayout = hsr_backward_row_layout(K, true, P);   // compact rows where the tile kernel that will run writes them and they save a line
+            gstride = hsr_grow_stride_l(glayout, K);
+        }
         char* sp = in.scratch;
         take(sp, grow, (size_t)P * gstride);
         StageTimer tm(HSR_STAGE_BWD_ZERO, stream);
@@ -685,6 +690,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         ra.rows = rows;
         ra.grow = grow;
         ra.grow_stride = gstride;
+        ra.grow_layout = glayout;
         StageTimer tm(HSR_STAGE_BWD_RENDER, stream);
 #ifdef HSR_ABLATE
         if (use_rows) {
@@ -694,7 +700,10 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         } else
 #endif
         if (geo) {
-            hsr_launch_render_backward_geo(ra, stream);
+            static const char* e_impl = getenv("HSR_BWD_IMPL");
+            static const bool old_sub = e_impl && !strcmp(e_impl, "sub");   // round 3's butterfly kernel (A/B timing, parity-tested)
+            if (old_sub) hsr_launch_render_backward_geo(ra, stream);
+            else hsr_launch_render_backward_qgeo(ra, stream);
         } else {
             hsr_launch_render_backward(ra, stream);
         }
@@ -714,7 +723,7 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
     pb.rows_kc = rows_kc; pb.K = K; pb.rows = rows; pb.inv = inv; pb.point_offsets = g.point_offsets;
     pb.out_mean2D = in.dL_dmean2D; pb.out_conic = in.dL_dconic; pb.out_opacity = in.dL_dopacity; pb.out_color = in.dL_dcolor;
     pb.out_semantics = in.dL_dsemantics; pb.out_depth = in.dL_ddepth;
-    pb.grow = grow; pb.grow_stride = gstride; pb.geo = geo ? 1 : 0;
+    pb.grow = grow; pb.grow_stride = gstride; pb.grow_layout = glayout; pb.geo = geo ? 1 : 0;
     if (pb.shs && (!in.dL_dsh || !in.campos)) {
         hsr_set_error("shs given without dL_dsh / campos");
         return HSR_ERR_INVALID_ARGUMENT;

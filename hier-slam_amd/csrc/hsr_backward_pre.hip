@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
         const int K = a.K, total = ng * K;
         const int dgi = 256 / K, dc = 256 - dgi * K;          // e += 256: row += dgi, column += dc (then one carry)
         int gi = (int)threadIdx.x / K, c = (int)threadIdx.x - gi * K;
-        const float* src = a.grow + (size_t)g0 * a.grow_stride + HSR_GROW_SEM0;
+        const float* src = a.grow + (size_t)g0 * a.grow_stride;   // + the column of channel c: hsr_grow_col
         float* dst = a.out_semantics + (size_t)g0 * K;
         int e = threadIdx.x;
         for (; e + 768 < total; e += 1024) {
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
                 // unconditional load (a culled Gaussian's lanes re-read the slab's first word, value discarded): a load under a
                 // divergent condition would be waited for where it is issued instead of four being in flight
                 const bool vs = s_vis[gi];
-                const float x = src[vs ? (size_t)gi * a.grow_stride + c : (size_t)0];
+                const float x = src[vs ? (size_t)gi * a.grow_stride + hsr_grow_col(a.grow_layout, K, c) : (size_t)0];
                 v[u] = vs ? x : 0.f;
                 gi += dgi; c += dc;
                 if (c >= K) { c -= K; gi++; }
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
         }
         for (; e < total; e += 256) {
             const bool vs = s_vis[gi];
-            const float x = src[vs ? (size_t)gi * a.grow_stride + c : (size_t)0];
+            const float x = src[vs ? (size_t)gi * a.grow_stride + hsr_grow_col(a.grow_layout, K, c) : (size_t)0];
             dst[e] = vs ? x : 0.f;
             gi += dgi; c += dc;
             if (c >= K) { c -= K; gi++; }
@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdArgs a)
         const float4 r0 = vis ? l0 : zero4, r1 = vis ? l1 : zero4;
         float d_r = 0.f, d_g = 0.f, d_b = 0.f, d_dep = 0.f, d_op = 0.f;
         if (!a.geo) {
-            const float* dr = a.grow + row * a.grow_stride + hsr_grow_direct0(a.K);  // r, g, b, depth, opacity (direct)
+            // r, g, b, depth, opacity (direct): channel columns K .. K + 4, five consecutive row columns under either layout
+            const float* dr = a.grow + row * a.grow_stride + hsr_grow_col(a.grow_layout, a.K, a.K);
             const float x0 = dr[0], x1 = dr[1], x2 = dr[2], x3 = dr[3], x4 = dr[4];
             if (vis) { d_r = x0; d_g = x1; d_b = x2; d_dep = x3; d_op = x4; }
         }

@@ -209,12 +209,16 @@ struct RenderBwdArgs {
     float* rows;          // rows mode: [R][ROW] per-instance sums (scratch)
     float* grow;          // packed mode: [P][grow_stride] one gradient row per Gaussian (scratch), else NULL
     int grow_stride;
+    int grow_layout;      // 0: classic packed row; 1: compact (hsr_tile_common.h, hsr_grow_col) — hsr_render_bwd_q.hip only
 };
 int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream);
 int hsr_launch_render_backward_mfma(const RenderBwdArgs& a, hipStream_t stream);
 int hsr_launch_render_backward_mom(const RenderBwdArgs& a, hipStream_t stream);   // K <= 27, packed mode: all sums on MFMA
 int hsr_launch_render_backward_sub(const RenderBwdArgs& a, hipStream_t stream);   // K <= 27, packed mode: 4x4 sub-block lists, rows merged per tile in LDS
 int hsr_launch_render_backward_geo(const RenderBwdArgs& a, hipStream_t stream);   // packed mode, geometry gradients only (grow_stride 16)
+int hsr_launch_render_backward_q(const RenderBwdArgs& a, hipStream_t stream);     // K <= 27, packed mode: round 4, both per-pixel factors in LDS panels, moments per chunk
+int hsr_launch_render_backward_qgeo(const RenderBwdArgs& a, hipStream_t stream);  // geometry gradients only, same scheme
+int hsr_backward_row_layout(int K_semantic, bool packed, int P);   // layout hsr_launch_render_backward will expect for this K (0 unless it takes the Q-panel kernel and the compact row saves a line)
 int hsr_launch_render_backward_subw(const RenderBwdArgs& a, hipStream_t stream);  // K > 27, packed mode: sub-block masks, channel passes
 int hsr_launch_render_backward_wide(const RenderBwdArgs& a, hipStream_t stream);  // semantic, K > 27: matrix-core channel passes
 int hsr_launch_render_backward_rows(const RenderBwdArgs& a, hipStream_t stream);  // returns the kernel's KC
@@ -257,6 +261,7 @@ struct PreBwdArgs {
     // packed mode: one atomically accumulated row per Gaussian (see hsr_grow_* in hsr_tile_common.h)
     const float* grow;
     int grow_stride;
+    int grow_layout;         // layout of the packed rows (RenderBwdArgs::grow_layout)
     int geo;                 // geometry-only rows (16 floats: columns 0..6, depth complete in column 6); out_color / out_opacity / out_semantics NULL
 };
 int hsr_launch_preprocess_backward(const PreBwdArgs& a, hipStream_t stream);

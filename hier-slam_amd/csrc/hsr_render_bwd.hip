@@ -262,6 +262,21 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a, int c0
 
 }  // namespace
 
+// Which kernel family takes packed rows of K semantic channels: shared by the launcher below and by hsr_api.hip, which sizes the rows
+// (the compact layout exists only in the Q-panel kernels).
+static bool backward_takes_q(int Ksem)
+{
+    static const char* impl = getenv("HSR_BWD_IMPL");
+    static const bool other = impl && (!strcmp(impl, "valu") || !strcmp(impl, "sub") || !strcmp(impl, "mfma") || !strcmp(impl, "mom"));
+    return !other && Ksem <= 27;
+}
+int hsr_backward_row_layout(int K_semantic, bool packed, int P)
+{
+    // (beyond 2^30 row elements the all-VALU kernel takes over, with classic rows: same test as in the launcher)
+    return (packed && backward_takes_q(K_semantic) && hsr_grow_compact_pays(K_semantic) &&
+            (size_t)P * (size_t)hsr_grow_stride_l(1, K_semantic) < ((size_t)1 << 30)) ? 1 : 0;
+}
+
 int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
 {
     const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
@@ -283,8 +298,11 @@ int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream)
         if (use_quad) return Ksem <= 27 ? hsr_launch_render_backward_mfma(a, stream) : hsr_launch_render_backward_wide(a, stream);
     }
 #endif
-    if (!force_valu && rows_fit_32bit && a.grow)
-        return Ksem <= 27 ? hsr_launch_render_backward_sub(a, stream) : hsr_launch_render_backward_subw(a, stream);
+    static const bool old_sub = impl && !strcmp(impl, "sub");   // round 3's butterfly kernel (A/B timing, parity-tested)
+    if (!force_valu && rows_fit_32bit && a.grow) {
+        if (Ksem > 27) return hsr_launch_render_backward_subw(a, stream);
+        return old_sub ? hsr_launch_render_backward_sub(a, stream) : hsr_launch_render_backward_q(a, stream);
+    }
     if (!a.semantic || a.K == 0) {
         render_bwd_kernel<0, true><<<grid, block, 0, stream>>>(a, 0);
         return HSR_OK;

@@ -275,3 +275,21 @@ __device__ __forceinline__ int flatten_sublist(int sb, int lane, uint8_t* s_list
 #define HSR_GROW_SEM0 16
 __host__ __device__ inline int hsr_grow_stride(int K) { return 16 + 16 * ((K + 5 + 15) / 16); }
 __host__ __device__ inline int hsr_grow_direct0(int K) { return HSR_GROW_SEM0 + K; }
+// Layout 1 ("compact", round 4; hsr_render_bwd_q.hip only): what an update costs is the number of 64-byte LINES it touches, and line 0 has nine
+// free columns.  The K + 5 channel columns [sem 0 .. K-1, r, g, b, depth(direct), opacity(direct)] are split: the LAST min(9, K + 5) of them
+// ride in columns 7..15 of line 0, the first R = K + 5 - that many follow from column 16.  K = 0: ONE line per row instead of two;
+// 12 <= K <= 20 (the NYU40 tree's K = 16): two instead of three.  hsr_grow_col gives the column of channel column ch under either layout.
+__host__ __device__ inline int hsr_grow_nl0(int K) { return K + 5 < 9 ? K + 5 : 9; }
+__host__ __device__ inline int hsr_grow_stride_l(int layout, int K)
+{
+    if (!layout) return hsr_grow_stride(K);
+    const int R = K + 5 - hsr_grow_nl0(K);
+    return 16 + 16 * ((R + 15) / 16);
+}
+__host__ __device__ inline int hsr_grow_col(int layout, int K, int ch)
+{
+    if (!layout) return HSR_GROW_SEM0 + ch;
+    const int R = K + 5 - hsr_grow_nl0(K);
+    return ch < R ? HSR_GROW_SEM0 + ch : 7 + (ch - R);
+}
+__host__ __device__ inline bool hsr_grow_compact_pays(int K) { return hsr_grow_stride_l(1, K) < hsr_grow_stride(K); }

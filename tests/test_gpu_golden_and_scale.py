@@ -175,10 +175,11 @@ def _ablate_env(**extra):
     return dict(os.environ, HSR_RAST_LIB=ABLATE_LIB, HSR_GLUE="ctypes", **extra)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "valu"])
+@pytest.mark.parametrize("impl", ["mfma", "valu", "sub"])
 def test_parity_alternate_kernels(impl):
     """kernel families are selected per process (HSR_FWD_IMPL / HSR_BWD_IMPL; defaults: per-lane forward and matrix-core backward
-    on 4x4 sub-block lists).  "valu" = quadrant-list per-lane kernels both ways — the product's fallback for the legacy accumulation
+    on 4x4 sub-block lists — since round 4 the Q-panel kernels of hsr_render_bwd_q.hip for K <= 27 and the geometry-only path; "sub" =
+    round 3's butterfly kernels, kept in the product library for A/B timing).  "valu" = quadrant-list per-lane kernels both ways — the product's fallback for the legacy accumulation
     mode and beyond 2^30 row elements; "mfma" = round 1's quadrant-list matrix-core backward, since round 3 in the ablate build only
     (csrc/experiments/).  Parity cases, each family in a child process"""
     import subprocess

@@ -18,7 +18,8 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 from hsr_utils.camera import replica_intrinsics, setup_camera_tensors  # noqa: E402
 from hsr_utils.synthetic import make_scene, make_upstream_grads  # noqa: E402
 
-W, H, K, P = 1200, 680, 26, 500000
+W, H, K, P = 1200, 680, int(os.environ.get("TRACE_K", "26")), 500000
+GEO = os.environ.get("TRACE_GEO", "0") == "1"   # tracking iteration: gradients for the means only
 k = replica_intrinsics(W, H)
 cam_cpu = setup_camera_tensors(W, H, k, np.eye(4))
 dev = torch.device("cuda")
@@ -27,7 +28,7 @@ sc = make_scene(P, W, H, K, k, seed=0)
 up = make_upstream_grads(W, H, K, seed=1)
 upd = [up[n].to(dev) for n in ("color", "semantic", "depth", "median", "opacity")]
 names = ("means3D", "colors_precomp", "semantics_precomp", "opacities", "scales", "rotations")
-leaf = {n: sc[n].to(dev).requires_grad_(True) for n in names}
+leaf = {n: sc[n].to(dev).requires_grad_((not GEO) or n == "means3D") for n in names}
 r = GaussianRasterizer_semantic(cam)
 for _ in range(3):
     m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
@@ -38,20 +39,27 @@ torch.cuda.synchronize()
 T = ((W + 15) // 16) * ((H + 15) // 16)
 n = min(T * 4, 16384) * 8
 buf = (C.c_ulonglong * n)()
-sub = os.environ.get("HSR_BWD_IMPL", "") != "mfma"   # default backward: the sub-block kernel; HSR_BWD_IMPL=mfma: the quadrant-list one
-rc = (_C._lib.hsr_debug_read_trace_sub if sub else _C._lib.hsr_debug_read_trace)(buf, n)
+impl = os.environ.get("HSR_BWD_IMPL", "")
+sub = impl != "mfma"   # default backward: round 4's Q-panel kernel; HSR_BWD_IMPL=sub: round 3's butterfly kernel; mfma: the quadrant-list one
+qk = impl == ""
+rc = (_C._lib.hsr_debug_read_trace_q if qk else (_C._lib.hsr_debug_read_trace_sub if sub else _C._lib.hsr_debug_read_trace))(buf, n)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
 a = a[a[:, 0] > 0]
 tot = a[:, 0].mean()
-print("kernel:", "render_bwd_sub_kernel" if sub else "render_bwd_mfma_kernel", " waves traced:", a.shape[0], "rc", rc)
+print("kernel:", ("render_bwd_q_kernel" if qk else "render_bwd_sub_kernel") if sub else "render_bwd_mfma_kernel", "K", K, "geo", GEO, " waves traced:", a.shape[0], "rc", rc)
 if sub:
-    names = ["total", "prologue", "stage+barriers", "loop(incl. flush)", "flush", "chunks", "group visits", "... with a pixel that accepts"]
+    names = ["total", "prologue", "stage+barriers", "loop(incl. flush)", "flush", "chunks", "wave iterations" if qk else "group visits", "chunk set-up (in loop)" if qk else "... with a pixel that accepts"]
     for i, nm in enumerate(names):
         print("%-18s mean %10.0f   p10 %10.0f   p90 %10.0f   max %10.0f" % (nm, a[:, i].mean(), np.percentile(a[:, i], 10), np.percentile(a[:, i], 90), a[:, i].max()))
     print("fractions of wave time: prologue %.2f  stage %.2f  loop %.2f (of which flush + emission %.2f)" % (
         a[:, 1].mean() / tot, a[:, 2].mean() / tot, a[:, 3].mean() / tot, a[:, 4].mean() / tot))
-    print("flush + emission cycles per chunk: %.0f ; (16-lane group, splat) visits per chunk: %.1f ; fraction of them in which a pixel accepts the splat: %.3f" % (
-        a[:, 4].sum() / a[:, 5].sum(), a[:, 6].sum() / a[:, 5].sum(), a[:, 7].sum() / a[:, 6].sum()))
+    if qk:
+        print("per chunk: set-up %.0f, visits %.0f, flush + emission %.0f cycles ; stage-A evaluations per chunk: %.2f ; visit-loop cycles per stage-A evaluation: %.0f" % (
+            a[:, 7].sum() / a[:, 5].sum(), (a[:, 3] - a[:, 4] - a[:, 7]).sum() / a[:, 5].sum(), a[:, 4].sum() / a[:, 5].sum(), a[:, 6].sum() / a[:, 5].sum(),
+            (a[:, 3] - a[:, 4] - a[:, 7]).sum() / a[:, 6].sum()))
+    else:
+        print("flush + emission cycles per chunk: %.0f ; (16-lane group, splat) visits per chunk: %.1f ; fraction of them in which a pixel accepts the splat: %.3f" % (
+            a[:, 4].sum() / a[:, 5].sum(), a[:, 6].sum() / a[:, 5].sum(), a[:, 7].sum() / a[:, 6].sum()))
 else:
     names = ["total", "prologue", "stage+barriers", "loop(no flush)", "flush", "emit", "visits", "accepted"]
     for i, nm in enumerate(names):
