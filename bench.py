@@ -73,16 +73,39 @@ def perturbed_w2c(rank):
     return w2c
 
 
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, sc, cam_cpu, up):
     """the oracle (a plain-C port of the reference's algorithm; the reference has no CPU renderer) on the host cores.
     Returns (cpu_baseline dict, (outputs, gradients, state) of the FIRST oracle render — the parity block's expectation)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = min(threads, int(os.environ.get("HSR_CPU_THREADS", "64")))  # OpenMP scaling of the oracle flattens out
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     kw = dict(colors_precomp=sc["colors_precomp"], semantics_precomp=sc["semantics_precomp"], scales=sc["scales"],
               rotations=sc["rotations"])
     g = {n: v.numpy() for n, v in up.items()}
+    # the thread count is chosen by measurement, not assumed (round 3 capped it at 64 of a 256-thread box): one untimed fwd+bwd render at
+    # 64 / 128 / all available threads (HSR_CPU_THREADS pins it), the fastest count runs the bounded sample
+    cands = [int(os.environ["HSR_CPU_THREADS"])] if os.environ.get("HSR_CPU_THREADS") else sorted({min(avail, c) for c in (64, 128, avail)})
+    probe = {}
+    if len(cands) > 1 and args.cpu_seconds > 0:
+        for c in cands:
+            tp = time.time()
+            o_, s_ = O.forward(cam_cpu, sc["means3D"], sc["opacities"], threads=c, **kw)
+            O.backward(s_, cam_cpu, sc["means3D"], g, threads=c, median_rule="forward", **kw)
+            s_.free()
+            probe[c] = time.time() - tp
+        threads = min(probe, key=probe.get)
+    else:
+        threads = cands[-1]
     n_done, t0, first = 0, time.time(), None
     while True:
         out, st = O.forward(cam_cpu, sc["means3D"], sc["opacities"], threads=threads, **kw)
@@ -102,8 +125,11 @@ def cpu_baseline(args, sc, cam_cpu, up):
         if el > args.cpu_seconds or n_done >= 50:
             break
     return ({"value": n_done / el, "unit": "renders/s", "cores": threads, "kind": "port",
+             "cpu_model": cpu_model_name(), "host_logical_cpus": os.cpu_count(), "cpus_available_to_the_process": avail,
+             "threads_probed_seconds_per_render": {str(c): round(v, 3) for c, v in probe.items()},
              "sample": "%d fwd+bwd renders of the same %dx%d / %d Gaussians / K=%d workload by the OpenMP C oracle "
-                       "(oracle/hsr_oracle.c) on all %d host threads" % (n_done, args.width, args.height, args.P, args.K, threads)},
+                       "(oracle/hsr_oracle.c) on %d host threads (the fastest of %s)" % (n_done, args.width, args.height, args.P, args.K, threads,
+                                                                                        "/".join(str(c) for c in cands))},
             first)
 
 
@@ -261,7 +287,7 @@ class Workload:
 
     names = ("means3D", "colors_precomp", "semantics_precomp", "opacities", "scales", "rotations")
 
-    def __init__(self, dev, W, H, P, K, kind, rank=0, world=1, device_tensors=True, behind_frac=0.0, geo=False):
+    def __init__(self, dev, W, H, P, K, kind, rank=0, world=1, device_tensors=True, behind_frac=0.0, geo=False, keyframes=1):
         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer_semantic
         from hsr_utils.camera import replica_intrinsics, setup_camera_tensors
         from hsr_utils.synthetic import make_scene, make_upstream_grads
@@ -273,9 +299,20 @@ class Workload:
         self.geo = geo
         self.up = make_upstream_grads(W, H, K, seed=1 + rank)
         self.exchange = None
+        self.stale = False
+        self.keyframes = max(1, int(keyframes))
+        self.steps_done = 0
         self.info = {}
         if device_tensors:
             cam = GaussianRasterizationSettings(**{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in self.cam_cpu.items()})
+            # N > 1: this rank's G keyframes of the mapping window (shard_keyframes: rank r renders keyframes r, r + N, ...): G cameras, G
+            # sets of upstream gradients, the same replicated Gaussians
+            self.kf = []
+            for g in range(1, self.keyframes):
+                cam_g = setup_camera_tensors(W, H, kmat, perturbed_w2c(rank + g * world))
+                up_g = make_upstream_grads(W, H, K, seed=1 + rank + g * world)
+                self.kf.append((GaussianRasterizer_semantic(GaussianRasterizationSettings(**{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cam_g.items()})),
+                                [up_g[n].to(dev) for n in ("color", "semantic", "depth", "median", "opacity")]))
             # geo: a tracking iteration (scripts/hierslam.py:1683-1860) — only the camera pose is optimised, so autograd asks for the
             # gradient of the (transformed) means alone and the backward takes its geometry-only path
             self.leaf = {n: self.sc[n].to(dev).requires_grad_(not geo or n == "means3D") for n in self.names}
@@ -293,21 +330,32 @@ class Workload:
         torch.cuda.empty_cache()
 
     def step(self):
+        """N = 1: one render (forward + backward).  N > 1: one optimizer step's worth of the mapping loop (scripts/hierslam.py:1966-2057) —
+        this rank's G keyframes rendered one after the other, their gradients accumulated in the exchange bucket, ONE exchange, and
+        (unless --stale-gradients) the wait for the sum: the point at which an Adam step could run."""
         leaf, dev = self.leaf, self.dev
-        means2D = torch.zeros(self.P, 3, device=dev, requires_grad=True)  # hierslam.py:895 retains this grad for densification
-        color, radii, sem, depth, median, opac = self.renderer(
-            means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"], colors_precomp=leaf["colors_precomp"],
-            scales=leaf["scales"], rotations=leaf["rotations"], semantics_precomp=leaf["semantics_precomp"])
-        self.info["node"] = color.grad_fn
-        self.info["radii"] = radii
         if self.exchange is not None:
-            self.exchange.begin_step(radii)  # the backward writes its gradient outputs into the next bucket; union-mask exchange starts
+            self.exchange.begin_step()   # the backwards write / accumulate their gradient outputs into the bucket
         else:
             for n in self.names:
                 leaf[n].grad = None
-        torch.autograd.backward([color, sem, depth, median, opac], self.upd)
+        for g in range(self.keyframes):
+            renderer, upd = (self.renderer, self.upd) if g == 0 else self.kf[g - 1]
+            means2D = torch.zeros(self.P, 3, device=dev, requires_grad=True)  # hierslam.py:895 retains this grad for densification
+            color, radii, sem, depth, median, opac = renderer(
+                means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"], colors_precomp=leaf["colors_precomp"],
+                scales=leaf["scales"], rotations=leaf["rotations"], semantics_precomp=leaf["semantics_precomp"])
+            if g == 0:
+                self.info["node"] = color.grad_fn
+                self.info["radii"] = radii
+            if self.exchange is not None:
+                self.exchange.add_keyframe(radii)
+            torch.autograd.backward([color, sem, depth, median, opac], upd)
         if self.exchange is not None:
             self.exchange.submit()
+            if not self.stale:
+                self.exchange.reduced(self.steps_done)   # the sum over all N x G keyframes has arrived
+        self.steps_done += 1
 
     def sync(self):
         if self.exchange is not None:
@@ -413,6 +461,12 @@ def main():
     ap.add_argument("--no-workloads", action="store_true", help="N = 1: only the headline workload, not the rest of the north star's list")
     ap.add_argument("--workload-steps", type=int, default=20, help="timed steps of each extra workload (at least 20)")
     ap.add_argument("--dense-exchange", action="store_true", help="N > 1: all-reduce every gradient row instead of the visible union")
+    ap.add_argument("--keyframes-per-rank", type=int, default=0,
+                    help="N > 1: keyframes each rank renders per optimizer step (gradients accumulated locally, ONE exchange per step); "
+                         "default 3 = the Replica configuration's mapping window of 24 keyframes over 8 ranks")
+    ap.add_argument("--stale-gradients", action="store_true",
+                    help="N > 1: two buckets, the exchange of step i overlaps the renders of step i + 1 — only valid for a caller that applies "
+                         "step i's gradients after rendering step i + 1 (the reference's loop does not: an Adam step sits between iterations)")
     ap.add_argument("--async-forward", action="store_true", help="opt-in non-blocking forward for the main workload too (diff_gaussian_rasterization.set_async_forward)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -464,14 +518,19 @@ def main():
     from hsr_utils.parallel import GradientExchange
 
     W, H, K, P = args.width, args.height, args.K, args.P
-    wl = Workload(dev, W, H, P, K, args.kind, rank, world, behind_frac=args.behind_frac, geo=args.geo)
+    G = 1 if world == 1 else (args.keyframes_per_rank if args.keyframes_per_rank > 0 else 3)
+    wl = Workload(dev, W, H, P, K, args.kind, rank, world, behind_frac=args.behind_frac, geo=args.geo, keyframes=G)
     exch = None
     if world > 1:
-        # N > 1: the one exchange step of the sharded path.  The leaves' .grad tensors are VIEWS of the exchange
-        # bucket (no pack copy); only the rows of Gaussians some rank saw are exchanged (visibility-sparse, bit-identical to the
-        # dense sum: hsr_utils/parallel.py); two buckets in flight, the all-reduce of step i overlaps render i + 1, the timed
-        # region ends with both drained.  As at N = 1 there is no optimizer inside a step.
-        exch = GradientExchange({"raster." + n: wl.leaf[n] for n in wl.names}, dev, depth=2, sparse=not args.dense_exchange)
+        # N > 1: the one exchange step of the sharded path, as a mapping step needs it: every rank renders its G keyframes
+        # of the window, the gradients accumulate in the exchange bucket (the leaves' .grad tensors are VIEWS of it: no pack copy), ONE
+        # exchange per optimizer step — only the rows of Gaussians some keyframe of some rank saw (visibility-sparse, bit-identical to the
+        # dense sum: hsr_utils/parallel.py) — and the step ends when the sum has arrived.  --stale-gradients: two buckets, the exchange of
+        # step i overlaps the renders of step i + 1 (round 3's default; not what the reference's loop allows).  As at N = 1 there is no
+        # optimizer inside a step.
+        exch = GradientExchange({"raster." + n: wl.leaf[n] for n in wl.names}, dev, depth=2 if args.stale_gradients else 1,
+                                sparse=not args.dense_exchange)
+        wl.stale = bool(args.stale_gradients)
     wl.exchange = exch
     if args.async_forward:
         import diff_gaussian_rasterization as dgr
@@ -494,13 +553,18 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         out = {
             "metric": "fwd+bwd renders/sec @1200x680, 500k Gaussians, 4-level tree; grad max-abs-err vs ref",
-            "value": world * args.steps / elapsed, "unit": "renders/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps,
+            "value": world * G * args.steps / elapsed, "unit": "renders/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(), "P": P, "visible": V, "num_rendered": R, "width": W, "height": H, "K": K,
-                       "parallelism": ("keyframe-parallel x%d: one keyframe per rank per step; gradients are views of the exchange bucket, "
-                                       "%s all-reduce, 2 buckets in flight (all-reduce of step i overlaps render i+1)"
-                                       % (world, "visibility-sparse" if not args.dense_exchange else "dense")) if world > 1 else "single GPU",
+                       "parallelism": ("keyframe-parallel x%d: a step = one optimizer step's worth of a mapping window of %d keyframes, %d per rank, "
+                                       "gradients accumulated in the exchange bucket (views, no pack copy), ONE %s all-reduce per step, %s"
+                                       % (world, world * G, G, "visibility-sparse" if not args.dense_exchange else "dense",
+                                          "2 buckets in flight: the exchange of step i overlaps the renders of step i + 1 (--stale-gradients)"
+                                          if args.stale_gradients else "the step ends when the sum has arrived (no overlap with the next step)"))
+                                      if world > 1 else "single GPU",
+                       "keyframes_per_rank": G, "renders_per_step": world * G,
+                       "exchange_mode": (None if world == 1 else ("stale-gradients (pipelined)" if args.stale_gradients else "accumulate-then-exchange")),
                        "api": "diff_gaussian_rasterization.GaussianRasterizer_semantic (torch autograd) -> C ABI"
                               + (", non-blocking forward (opt-in)" if args.async_forward else "")},
         }

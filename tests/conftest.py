@@ -38,8 +38,12 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         return
     worst = {}
     for name, st in harness.OBSERVED:
-        w = worst.setdefault(name, dict(cases=0, err_over_max=0.0, max_abs_err=0.0, elementwise={}))
+        w = worst.setdefault(name, dict(cases=0, err_over_max=0.0, max_abs_err=0.0, elementwise={}, worst_test="", worst_elementwise_test=""))
         w["cases"] += 1
+        if st["err_over_max"] >= w["err_over_max"]:
+            w["worst_test"] = st.get("test", "")
+        if st["elementwise"].get("0.1", 0.0) >= w["elementwise"].get("0.1", 0.0):
+            w["worst_elementwise_test"] = st.get("test", "")
         w["err_over_max"] = max(w["err_over_max"], st["err_over_max"])
         w["max_abs_err"] = max(w["max_abs_err"], st["max_abs_err"])
         for f, v in st["elementwise"].items():
@@ -52,6 +56,11 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         w = worst[name]
         tr.write_line("%-28s n=%-4d err/max %.2e   element-wise at floor 1/0.1/0.01/0.001: %s" % (
             name, w["cases"], w["err_over_max"], " ".join("%.1e" % w["elementwise"].get(f, 0.0) for f in ("1", "0.1", "0.01", "0.001"))))
+    # which test holds the worst comparison of the three gradients with the least margin: the named cases are also
+    # run against the truth build in tests/test_gpu_truth.py::test_worst_margin_cases_of_the_suite
+    for name in ("grad means3D", "grad scales", "grad rotations"):
+        if name in worst:
+            tr.write_line("worst %-15s tensor-wide: %s ; element-wise at floor 0.1: %s" % (name, worst[name]["worst_test"], worst[name]["worst_elementwise_test"]))
     try:
         import test_gpu_parity
         if test_gpu_parity.TIE_BOUNDED:

@@ -1,5 +1,7 @@
 """Runs one forward+backward through the public torch API on the GPU and through the oracle on the CPU,
 returning comparable dicts.  Used by the -m gpu parity tests."""
+import os
+
 import numpy as np
 import torch
 
@@ -210,6 +212,7 @@ def assert_close(name, got, exp, rtol=RTOL, atol=ATOL, floor_frac=None, elementw
     else:
         resid = np.maximum(np.abs(got - exp) - np.broadcast_to(np.asarray(allowance, np.float64), got.shape), 0.0)
         st = error_stats(exp + resid, exp)
+    st["test"] = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]   # which test made this comparison (the summary names the worst ones)
     OBSERVED.append((name, st))
     err, mx = st["max_abs_err"], st["max_abs_exp"]
     lim = atol + rtol * mx

@@ -11,6 +11,7 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "libhsr_oracle.so")
 _SO64 = os.path.join(_ROOT, "oracle", "libhsr_oracle_f64.so")   # the "truth" build: same fp32 lists, arithmetic in double
+_SOFMA = os.path.join(_ROOT, "oracle", "libhsr_oracle_fma.so")  # the sensitivity build: fp32, FMA contraction allowed everywhere
 _libs = {}
 
 FIELDS = dict(depths=0, means2D=1, conic_opacity=2, cov3D=3, rgb=4, clamped=5, radii=6, tiles_touched=7,
@@ -20,7 +21,7 @@ IMG_BOUND_PLANES = ("color", "depth", "opacity", "semantic", "final_T", "mask") 
 
 
 def build(force=False, precision="f32"):
-    so = _SO64 if precision == "f64" else _SO
+    so = {"f64": _SO64, "fma": _SOFMA}.get(precision, _SO)
     srcs = [os.path.join(_ROOT, "oracle", n) for n in ("hsr_oracle.c", "hsr_oracle_la.h")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-B", os.path.basename(so)],
@@ -36,7 +37,8 @@ class Bounds(C.Structure):
 
 
 def lib(precision="f32"):
-    """precision "f32": the oracle; "f64": the truth build (images, final_T and gradients come back as float64)"""
+    """precision "f32": the oracle; "f64": the truth build (images, final_T and gradients come back as float64); "fma": the
+    contracted-FMA sensitivity build (oracle/Makefile) — never a parity checker"""
     L = _libs.get(precision)
     if L is None:
         L = C.CDLL(build(precision=precision))

@@ -40,6 +40,66 @@ def test_random_configuration(name, cfg):
     _compare(cam, sc, up, semantic, variant, None)
 
 
+# Round 4: the generator above only ever draws scales + rotations with precomputed colours at scale_modifier 1
+# through centred intrinsics.  A second generator — separate, so that the named cases of the first keep their seeds — also draws the
+# input variant (cov3D_precomp instead of scales / rotations), the colour source (SH of degree 0..3 instead of colors_precomp), the
+# scale modifier and ScanNet-like intrinsics (fx != fy, principal point off the centre).
+def _cases_v2(n=24, seed=4104):
+    g = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        W, H = int(g.integers(17, 200)), int(g.integers(17, 150))
+        P = int(g.choice([7, 63, 300, 1200, 2500]))
+        semantic = bool(g.random() < 0.8)
+        K = int(g.choice([0, 1, 3, 11, 16, 26, 27, 28, 31, 40, 53, 74])) if semantic else 0
+        kind = str(g.choice(["slam", "aniso"]))
+        sm = float(g.choice([0.3, 1.0, 3.0, 12.0]))
+        bg = tuple(float(x) for x in g.choice([0.0, 1.0, 0.3], size=3))
+        behind = float(g.choice([0.0, 0.0, 0.3]))
+        variant = str(g.choice(["sr", "cov"]))
+        sh_deg = int(g.choice([-1, -1, 0, 1, 2, 3]))        # -1: colors_precomp
+        mod = float(g.choice([0.6, 1.0, 1.7]))
+        off_centre = bool(g.random() < 0.5)
+        name = "v2_%02d_%dx%d_P%d_K%d_%s_x%g_%s_%s_mod%g_%s" % (i, W, H, P, K, kind, sm, variant, "sh%d" % sh_deg if sh_deg >= 0 else "rgb", mod,
+                                                           "offc" if off_centre else "ctr")
+        out.append((name, (W, H, P, K, kind, sm, semantic, variant, bg, behind, sh_deg, mod, off_centre)))
+    return out
+
+
+CASES_V2 = _cases_v2(int(os.environ.get("HSR_FUZZ_CASES_V2", "24")), int(os.environ.get("HSR_FUZZ_SEED_V2", "4104")))
+
+
+def build_v2(name, cfg):
+    import torch
+    from hsr_utils.camera import setup_camera_tensors
+    from hsr_utils.synthetic import make_scene, make_upstream_grads
+    W, H, P, K, kind, sm, semantic, variant, bg, behind, sh_deg, mod, off_centre = cfg
+    seed = zlib.crc32(name.encode()) % 1000
+    if off_centre:
+        k = np.array([[0.97 * W, 0.0, 0.41 * W], [0.0, 1.07 * W, 0.57 * H], [0.0, 0.0, 1.0]])
+        w2c = scenes.tilted_w2c(0.15, (0.05, 0.1, 0.1))
+        cam = setup_camera_tensors(W, H, k, w2c)
+        cam["bg"] = torch.tensor(bg, dtype=torch.float32)
+        sc = make_scene(P, W, H, K, k, seed=seed, kind=kind, scale_mult=sm, w2c=w2c, behind_frac=behind)
+        up = {n: v * float(W * H) for n, v in make_upstream_grads(W, H, K, seed=1).items()}
+    else:
+        cam, sc, up = scenes.build(W, H, P, K, seed=seed, kind=kind, scale_mult=sm, bg=bg, behind_frac=behind)
+    cam = dict(cam, scale_modifier=float(mod))
+    extra = {}
+    if variant == "cov":
+        extra["cov3D_precomp"] = scenes.cov3d_from_scene(sc, mod)     # what the scale modifier would have made of the scales
+    if sh_deg >= 0:
+        cam["sh_degree"] = sh_deg
+        extra["shs"] = scenes.random_sh(P, 16, seed=seed + 1)
+    return cam, sc, up, semantic, variant, (extra or None)
+
+
+@pytest.mark.parametrize("name,cfg", CASES_V2, ids=[c[0] for c in CASES_V2])
+def test_random_configuration_variants(name, cfg):
+    cam, sc, up, semantic, variant, extra = build_v2(name, cfg)
+    _compare(cam, sc, up, semantic, variant, extra)
+
+
 # the legacy accumulation mode (no scratch: atomics straight into the reference's six arrays) runs the all-VALU quadrant-list backward
 # (hsr_render_bwd.hip) since round 3: every third case of the default list through it
 @pytest.mark.parametrize("name,cfg", CASES[::3], ids=[c[0] for c in CASES[::3]])

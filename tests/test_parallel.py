@@ -182,6 +182,90 @@ def _exchange_checks(rank, world):
     for v in ex.reduced(4):
         assert torch.equal(v, torch.full_like(v, 3.0))
     assert ex.stats()["copied_tensors"] == 3
+    _accumulate_checks(rank, world, leaves, ref_leaves, gen)
+
+
+def _accumulate_checks(rank, world, leaves, ref_leaves, gen):
+    """One optimizer step = G keyframes per rank accumulated locally, ONE exchange (a bucket view is handed
+    out once per step and name).  The result must equal the dense sum of the 2 G single-keyframe gradients BIT FOR BIT: each rank adds
+    its keyframes in order in fp32 (autograd's in-place accumulation into the adopted bucket slice), then a + b over the two ranks."""
+    from hsr_utils.parallel import GradientExchange, allreduce_gradients
+    P = next(iter(leaves.values())).shape[0]
+    ex = GradientExchange(leaves, "cpu", sparse=True, dense_above=0.9)           # depth 1: reduced() waits, nothing overlaps a later step
+    G = 3
+    rows = {0: [(0, 40), (30, 70), (100, 120)], 1: [(20, 60), (110, 140), (0, 10)]}  # union over 2 x 3 keyframes: [0, 70) + [100, 140) = 110 rows
+    for step in range(2):
+        local = [torch.zeros_like(t) for t in leaves.values()]
+        ex.begin_step()
+        for k in range(G):
+            lo, hi = rows[rank][k]
+            radii = torch.zeros(P, dtype=torch.int32)
+            radii[lo:hi] = 2
+            grads = []
+            for t in leaves.values():
+                g = torch.randn(t.shape, generator=gen)
+                g[radii <= 0] = 0.0
+                grads.append(g)
+            ex.add_keyframe(radii)
+            _ToyRender.apply(*leaves.values(), *grads).backward()
+            for acc, g in zip(local, grads):
+                acc += g                                  # the same fp32 additions, in the same order
+        for i, t in enumerate(leaves.values()):           # still the bucket's slice after three accumulated backwards
+            assert t.grad.data_ptr() == ex.buckets[0].views[i].data_ptr()
+            assert torch.equal(t.grad, local[i])
+        before = ex.stats()
+        ex.submit()
+        after = ex.stats()
+        assert after["sparse_steps"] - before["sparse_steps"] == 1 and after["copied_tensors"] == before["copied_tensors"]
+        for r, acc in zip(ref_leaves, local):
+            r.grad = acc.clone()
+        allreduce_gradients(ref_leaves)
+        for v, r in zip(ex.reduced(step), ref_leaves):
+            assert torch.equal(v, r.grad), "accumulate-then-exchange differs from the dense sum of the 2 x %d keyframe gradients" % G
+    st = ex.stats()
+    assert st["keyframes_per_step"] == G and abs(st["union_fraction"] - 110 / P) < 1e-9, st
+    # two rasterizer nodes on the same leaves in ONE graph, and a second backward through it: 1 + 10 per rank, twice (ADVICE r3: was 2 and 20)
+    ex.begin_step()
+    ones = [torch.ones_like(t) for t in leaves.values()]
+    tens = [torch.full_like(t, 10.0) for t in leaves.values()]
+    full = torch.full((P,), 5, dtype=torch.int32)
+    ex.add_keyframe(full)
+    loss = _ToyRender.apply(*leaves.values(), *ones) + _ToyRender.apply(*leaves.values(), *tens)
+    loss.backward(retain_graph=True)
+    for t in leaves.values():
+        assert torch.equal(t.grad, torch.full_like(t, 11.0))
+    loss.backward()
+    for t in leaves.values():
+        assert torch.equal(t.grad, torch.full_like(t, 22.0))
+    ex.submit()
+    for v in ex.reduced(2):
+        assert torch.equal(v, torch.full_like(v, 22.0 * world))
+    # a gradient from another producer (a regulariser: non-zero on rows no keyframe saw) in a step whose union is sparse: the flag byte of the
+    # mask makes EVERY rank exchange the bucket whole — the rows outside the union are summed, not left at their local value
+    ex.begin_step()
+    few = torch.zeros(P, dtype=torch.int32); few[:10] = 1
+    grads = [torch.zeros_like(t) for t in leaves.values()]
+    for g in grads:
+        g[:10] = float(rank + 1)
+    ex.add_keyframe(few)
+    reg = sum((t * float(rank + 1)).sum() for t in leaves.values()) if rank == 0 else 0.0    # only rank 0 has the extra producer
+    (_ToyRender.apply(*leaves.values(), *grads) + reg).backward()
+    before = ex.stats()["foreign_dense_steps"]
+    ex.submit()
+    for v in ex.reduced(3):
+        e = torch.full_like(v, 1.0)          # rank 0's regulariser everywhere
+        e[:10] += 1.0 + 2.0                  # + both ranks' rasterizer rows
+        assert torch.equal(v, e), (v[:12], e[:12])
+    assert ex.stats()["foreign_dense_steps"] - before == 1
+    # a step that raises leaves no sink behind
+    from diff_gaussian_rasterization import _C
+    try:
+        with ex.step_scope():
+            raise ValueError("backward failed")
+    except ValueError:
+        pass
+    assert _C._gradient_sink is None
+    ex.drain()
 
 
 def test_gradient_allreduce_gloo_world2():
