@@ -9,8 +9,8 @@
 // ~70 vector instructions of a visit — the part of the kernel that does not depend on K.  Six of the
 // seven are polynomial moments of ONE per-pixel number, gda = G * dL/dalpha:
 //     sum gda,  sum gda*dx,  sum gda*dy,  sum gda*dx^2,  sum gda*dx*dy,  sum gda*dy^2          (dx = splat centre - pixel centre)
-// A visit now just stores its two per-pixel factors — w (the blend weight, as before) and gda — into two LDS panels
-// [16 chunk rows][64 pixels] and moves on: 33 vector instructions.  At the end of the chunk
+// A visit now just stores its two per-pixel factors — w (the blend weight, as before) and gda — into LDS and moves on: ~28 vector
+// instructions.  At the end of the chunk
 //   * W . G on the matrix cores gives the K + 5 channel sums (as before);
 //   * lane (row, group) reads the group's 16 gda values of that row and forms their six moments ABOUT THE SUB-BLOCK'S CENTRE
 //     (|u|, |v| <= 1.5 px, the basis values are small exact constants, the sums are separable: 57 instructions per lane and
@@ -20,16 +20,25 @@
 //     Round 2 summed RAW moments (sum q dx, |dx| up to the splat's extent) and cancelled afterwards: 15x the error of the
 //     reference's per-pixel formulation on elongated splats.  Here the cancelling products (A' ex against
 //     B'/2 ey) are combined ONCE per (row, group) in a single FMA — the same rounding the reference pays per pixel — and what
-//     is summed in fp32 before a cancellation is bounded by 1.5 px, not by the splat's size; tests/test_gpu_truth.py is the gate.
-//   * the seventh value (the median-depth gradient: one pixel -> one splat, ever) is a masked LDS float add into the row's
-//     padding word.
+//     is summed in fp32 before a cancellation is bounded by 1.5 px, not by the splat's size; tests/test_gpu_truth.py is the gate
+//     (all of its cases, both 3 000-case fuzz seeds: DESIGN.md §2).
+//   * the seventh value (the median-depth gradient: one pixel -> one splat, ever) never enters the loop: a per-batch table (see
+//     "median" in the kernel).
 // Idle groups (a group whose list is shorter than the longest of the four) visit a DUMMY entry of opacity 0 and write to a
-// dummy panel row: no validity predicate, no exec juggling in the loop.  Inactive pixels are handled by masking alpha and G
-// to zero (T * rcp(1 - 0) = T, fma(0, x, R) = R): two selects per visit instead of four.  The next visit's record is
-// fetched while this one is evaluated.
+// dummy segment: no validity predicate, no exec juggling in the loop.  Inactive pixels are handled by masking alpha and G
+// to zero (T * rcp(1 - 0) = T, fma(0, x, R) = R): two selects per visit instead of four.  The loop is software-pipelined by
+// hand (record of visit i + 2 in flight, alpha stage of visit i + 1, blend stage of visit i).
 //
-// Cost of the panels: 2 x 16 x 68 floats per wave = 37 KB per workgroup, 53 KB in all: three workgroups per CU (168 registers
-// each) instead of four.
+// What the measurements of the round say (EXPERIMENTS.md §10; profiles/r04_*):
+//   * the kernels are bound by instruction ISSUE — a wave issues one instruction every 7-10 cycles whatever its kind, a SIMD ~2.4
+//     cycles per instruction with four waves — so a visit costs its instruction count, and the chip delivers that count times the
+//     waves in flight: the first version of this file (two [16][64] row panels, 53 KB of LDS, three workgroups per CU) had 25 % fewer
+//     vector instructions than round 3's kernel and exactly its run time.  Hence the panels are stored as SEGMENTS, one per
+//     (row, group) pair a chunk actually visits (29.5 of 64 on average): 40 KB, four workgroups per CU, nothing to clear;
+//   * with K > 0 the kernel is bound by its gradient atomics, not by any of this: three 64-byte lines per (splat, quadrant) row,
+//     4.57 M requests at the headline = 0.225 ms at the memory side's rate, 0.28 measured with or without the instruction savings.
+//     What helps there is fewer LINES: compact rows (hsr_tile_common.h) make K = 0 one line instead of two and 12 <= K <= 20 two
+//     instead of three; K = 26 needs 36 floats and stays at three.
 #include "hsr_tile_common.h"
 #include <stdlib.h>
 #include <string.h>

@@ -185,10 +185,10 @@ def set_async_forward(on):
 class LazyRendered:
     """num_rendered of a forward call that ran ahead of the device: an int-like that fetches the count (and checks that it fitted
     the binning buffer) the first time it is used as a number"""
-    __slots__ = ("_ticket", "_value", "_key", "_stream")
+    __slots__ = ("_ticket", "_value", "_key", "_stream", "_error")
 
     def __init__(self, ticket, key, stream):
-        self._ticket, self._value, self._key, self._stream = ticket, None, key, stream
+        self._ticket, self._value, self._key, self._stream, self._error = ticket, None, key, stream, None
 
     def ready(self):
         """has the device written the count yet? (never blocks)"""
@@ -197,6 +197,8 @@ class LazyRendered:
     def _end(self, block):
         if self._value is not None:
             return self._value
+        if self._error is not None:
+            raise RuntimeError(self._error)        # reported once already: the same answer to whoever asks again
         if isinstance(self._ticket, bytes):
             rc, rendered, err = _ext.forward_end(self._ticket, bool(block), int(self._stream))
         else:
@@ -206,9 +208,11 @@ class LazyRendered:
             return None
         if rc == HSR_ERR_BUFFER_TOO_SMALL:
             _binning_hint[self._key] = int(rendered)      # the next forward of this size gets room for it
-            raise RuntimeError("diff_gaussian_rasterization (async forward): " + err)
+            self._error = "diff_gaussian_rasterization (async forward): " + err
+            raise RuntimeError(self._error)
         if rc < 0:
-            raise RuntimeError("diff_gaussian_rasterization (async forward): hsr_forward_end failed (code %d): %s" % (rc, err))
+            self._error = "diff_gaussian_rasterization (async forward): hsr_forward_end failed (code %d): %s" % (rc, err)
+            raise RuntimeError(self._error)
         self._value = int(rc)
         _binning_hint[self._key] = self._value
         return self._value
@@ -217,6 +221,15 @@ class LazyRendered:
         return self._end(True)
 
     __index__ = __int__
+
+    def __bool__(self):
+        return int(self) != 0
+
+    def __sub__(self, other):
+        return int(self) - other
+
+    def __rsub__(self, other):
+        return other - int(self)
 
     def __eq__(self, other):
         return int(self) == other
@@ -260,6 +273,19 @@ class LazyRendered:
 
     def __floordiv__(self, other):
         return int(self) // other
+
+
+# The newest unresolved count of every (device, P, W, H): a forward that ran ahead and was never followed by a backward (a
+# visualisation render outside no_grad) would otherwise never report an overflow — its outputs are NaN by then — and never correct the
+# binning hint, so every later frame of that size would overflow again.  The next run-ahead forward of the same key
+# resolves it first: an overflow of frame i is raised, loudly, at the forward of frame i + 1 at the latest.
+_unresolved = {}
+
+
+def _resolve_previous(key):
+    prev = _unresolved.pop(key, None)
+    if prev is not None and prev._value is None and prev._error is None:
+        prev._end(True)
 
 
 # Gradient sink (hsr_utils/parallel.py GradientExchange): a callable (name, shape, device) -> tensor | None that may hand the
@@ -378,6 +404,8 @@ def _forward_common(semantic, background, means3D, colors, semantics, opacity, s
     if run_ahead:
         key = (means3D.device.index, int(means3D.size(0)), int(image_width), int(image_height))
         run_ahead = key[1] > 0 and key in _binning_hint
+        if run_ahead:
+            _resolve_previous(key)
     if _ext is not None and means3D.is_cuda:
         stream = torch.cuda.current_stream(means3D.device).cuda_stream
         res = _ext.forward_common(bool(semantic), background, means3D, colors, semantics, opacity, scales, rotations,
@@ -385,7 +413,8 @@ def _forward_common(semantic, background, means3D, colors, semantics, opacity, s
                                   int(image_height), int(image_width), sh, int(degree), campos, bool(prefiltered), bool(debug),
                                   stream, run_ahead)
         if res[0] == HSR_PENDING:
-            return (LazyRendered(res[10], key, stream),) + tuple(res[1:10])
+            lz = _unresolved[key] = LazyRendered(res[10], key, stream)
+            return (lz,) + tuple(res[1:10])
         return tuple(res[:10])
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:60-62
@@ -445,7 +474,8 @@ def _forward_common(semantic, background, means3D, colors, semantics, opacity, s
             for g_ in (geom, binning, img):
                 g_.close()
         if rc == HSR_PENDING and ticket is not None:
-            return LazyRendered(ticket, key, stream), out_color, out_aux, out_depth, out_median, out_opacity, radii, geom.t, binning.t, img.t
+            lz = _unresolved[key] = LazyRendered(ticket, key, stream)
+            return lz, out_color, out_aux, out_depth, out_median, out_opacity, radii, geom.t, binning.t, img.t
         if rc < 0:
             _fail(rc, "rasterize_gaussians_semantic" if semantic else "rasterize_gaussians")
         if P:

@@ -34,6 +34,10 @@ def set_async_forward(on):
     return _C.set_async_forward(on)
 
 
+import threading
+
+_caller = threading.local()   # the grad mode of the thread that called rasterize_gaussians*(): see _Rasterize.forward
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -80,7 +84,9 @@ class _Rasterize(torch.autograd.Function):
                   rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
                   rs.debug)
         # non-blocking forward (opt-in, _C.set_async_forward): only where a backward will follow and resolve num_rendered
-        ahead = dict(run_ahead=True) if (_C._async_forward and any(ctx.needs_input_grad)) else {}
+        # (needs_input_grad reflects the inputs' requires_grad whatever the caller's grad mode: under torch.no_grad() no backward can
+        # follow — and inside forward() the grad mode is always off, so the wrappers below note the caller's)
+        ahead = dict(run_ahead=True) if (_C._async_forward and getattr(_caller, "grad_enabled", True) and any(ctx.needs_input_grad)) else {}
         if semantic:
             args = (rs.bg, means3D, colors_precomp, semantics_precomp) + common
             (num_rendered, color, aux, depth, median_depth, final_opacity, radii, geom, binning, img) = _call(
@@ -136,12 +142,14 @@ class _Rasterize(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    _caller.grad_enabled = torch.is_grad_enabled()
     return _Rasterize.apply(False, means3D, means2D, sh, colors_precomp, None, opacities, scales, rotations,
                             cov3Ds_precomp, raster_settings)
 
 
 def rasterize_gaussians_semantic(means3D, means2D, sh, colors_precomp, semantics_precomp, opacities, scales, rotations,
                                  cov3Ds_precomp, raster_settings):
+    _caller.grad_enabled = torch.is_grad_enabled()
     return _Rasterize.apply(True, means3D, means2D, sh, colors_precomp, semantics_precomp, opacities, scales, rotations,
                             cov3Ds_precomp, raster_settings)
 

@@ -114,10 +114,11 @@ def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
             return float(d.max() / mx), float((d / np.maximum(np.abs(t), fl * mx)).max())
         h = dist(got)
         def dist_pair(a, b):   # the fp32 oracle against the truth with one upstream gradient alone (harness.fp32_error_samples)
+            # an ABSOLUTE error of one term mix of the same sum, measured on the scale HIP's distance is measured on — the full gradient's
+            # maximum and floor (normalised by the single-upstream run's own, smaller scale it inflated the floor)
             b = np.asarray(b, np.float64).reshape(t.shape)
-            mb = max(float(np.abs(b).max()), 1e-30)        # relative to that run's own gradient scale
             d = np.abs(np.asarray(a, np.float64).reshape(t.shape) - b)
-            return float(d.max() / mb), float((d / np.maximum(np.abs(b), fl * mb)).max())
+            return float(d.max() / mx), float((d / np.maximum(np.abs(t), fl * mx)).max())
         floor = [max(x) for x in zip(dist(gr_o[key]), *[dist(m[key]) for m in truth["m"]], *[dist_pair(go_[key], gt_[key]) for go_, gt_ in truth["s"]])]
         for hv, fv, what in zip(h, floor, ("tensor-wide", "element-wise")):
             assert hv <= max(1e-4, 2.0 * fv + 2e-5), "%s: %s distance from the truth %.3e, fp32 noise floor %.3e" % (name, what, hv, fv)
@@ -565,6 +566,44 @@ def test_non_blocking_forward_runs_ahead_and_fails_loudly_when_the_buffer_was_to
         dgr.set_async_forward(prev)
 
 
+def test_non_blocking_forward_without_a_backward_is_resolved_by_the_next_forward_of_its_size():
+    """a run-ahead forward that no backward follows (a visualisation render outside no_grad) used to keep its count — and
+    a possible overflow, with all-NaN outputs — to itself for ever, and never corrected the binning hint.  The next run-ahead forward
+    of the same (device, P, W, H) now resolves it first: the overflow is raised there, once, the hint is corrected, and the call after
+    that fits.  LazyRendered also answers bool() and subtraction like the int it stands for."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    W, H, P, K = 120, 90, 1500, 11
+    cam, sc, up = scenes.build(W, H, P, K, seed=8, kind="slam")
+    key = (dev.index, P, W, H)
+    ref = _fwd_bwd(cam, sc, up, dev)
+    prev = dgr.set_async_forward(True)
+    try:
+        R = _C._binning_hint[key]
+        leaf, outs = _render_sem(cam, sc, dev)                     # runs ahead, fits, nobody calls backward
+        lz = outs[0].grad_fn.num_rendered
+        assert isinstance(lz, _C.LazyRendered) and lz._value is None
+        leaf, outs_b = _render_sem(cam, sc, dev)                   # the next forward of this size resolved it
+        assert lz._value == R and bool(lz) and lz - 1 == R - 1 and R - lz == 0
+        outs_b[0].sum().backward()
+        _C._binning_hint[key] = 8                                  # now one that overflows and is never followed by a backward
+        leaf, outs_c = _render_sem(cam, sc, dev)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(outs_c[0]).all())
+        with pytest.raises(RuntimeError, match="does not fit the binning buffer"):
+            _render_sem(cam, sc, dev)                              # raised HERE, at the latest
+        assert _C._binning_hint[key] == R
+        leaf, outs_d = _render_sem(cam, sc, dev)                   # not raised twice; this one fits
+        outs_d[0].sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(outs_d[0].detach(), ref[0][0])
+        with pytest.raises(RuntimeError, match="does not fit the binning buffer"):
+            int(outs_c[0].grad_fn.num_rendered)                    # whoever asks the failed one again gets the same answer
+    finally:
+        dgr.set_async_forward(prev)
+
+
 def test_non_blocking_count_overwritten_after_a_ring_of_unresolved_forwards_fails_at_once():
     """The non-blocking forward's counts live in a ring of 256 host-mapped slots per device.  A forward whose count nobody resolved
     while 256 later ones ran ahead has lost it: resolving it then must raise immediately (not wait 10 s for a sequence number that
@@ -581,8 +620,13 @@ def test_non_blocking_count_overwritten_after_a_ring_of_unresolved_forwards_fail
         leaf0, outs0 = _render_sem(cam, sc, dev)      # never resolved ...
         first = outs0[0].grad_fn.num_rendered
         assert isinstance(first, _C.LazyRendered)
-        for _ in range(260):                          # ... while a whole ring of later forwards runs ahead (each resolved by its backward)
-            leaf, outs = _render_sem(cam, sc, dev)
+        # ... while a whole ring of later forwards OF ANOTHER SIZE runs ahead (each resolved by its backward).  (A later run-ahead forward
+        # of the SAME size resolves the pending count first, since round 4: see the next test.)
+        cam2, sc2, up2 = scenes.build(W, H, P + 1, K, seed=4, kind="slam")
+        _fwd_bwd(cam2, sc2, up2, dev)
+        for _ in range(260):
+            leaf, outs = _render_sem(cam2, sc2, dev)
+            assert isinstance(outs[0].grad_fn.num_rendered, _C.LazyRendered)
             outs[0].sum().backward()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -70,6 +70,26 @@ def test_hip_and_oracle_are_equidistant_from_the_truth(cfg):
     _check("%dx%d_P%d_K%d_%s_x%g_s%d" % cfg, truth_report(cam, sc, up, semantic=True, atomics_seeds=SEEDS if P <= 5000 else ()))
 
 
+# The comparisons of the default suite with the least margin (tests/conftest.py names them at the end of every run: "worst grad means3D /
+# scales / rotations").  As of round 4: dL_dmeans3D element-wise — fuzz case 05 (63 big anisotropic splats on a 29 x 121
+# image); dL_dscales — fuzz case 21 (2 500 elongated splats, 136 x 141); dL_drotations — case v2_14 of the variants generator (scale modifier
+# 1.7).  Their HIP-vs-truth and oracle-vs-truth distances go on record in gpurun_out/truth_report.json with the other cases.
+WORST_MARGIN = [("v1", "05_29x121_P63_K26_aniso_x12"), ("v1", "21_136x141_P2500_K28_aniso_x3"), ("v1", "12_127x18_P1_K16_slam_x60"),
+                ("v2", "v2_14_89x140_P2500_K11_aniso_x1_sr_rgb_mod1.7_ctr")]
+
+
+@pytest.mark.parametrize("case", WORST_MARGIN, ids=[c[1] for c in WORST_MARGIN])
+def test_worst_margin_cases_of_the_suite(case):
+    gen, name = case
+    if gen == "v1":
+        cam, sc, up, semantic, variant = _scene(name, 2024, 28)
+        extra = None
+    else:
+        from test_gpu_fuzz import CASES_V2, build_v2
+        cam, sc, up, semantic, variant, extra = build_v2(name, dict(CASES_V2)[name])
+    _check("worst-margin " + name, truth_report(cam, sc, up, semantic=semantic, variant=variant, extra=extra, atomics_seeds=SEEDS))
+
+
 def teardown_module(module):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
