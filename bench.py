@@ -275,6 +275,10 @@ EXTRA_WORKLOADS = [
     (1200, 680, 300000, 26, "slam", "300k (BASELINE.json configs[1]: ~300k Gaussians)"),
     (1200, 680, 2000000, 26, "slam", "2M"),
     (1200, 680, 500000, 16, "slam", "K=16 (ScanNet NYU40 4-level tree)"),
+    # the backward tile kernel without its K-dependent part: K = 0 with every gradient, and the geometry-only backward
+    # of a TRACKING iteration (only the camera pose is optimised: scripts/hierslam.py:1683-1860 — the loop Hier-SLAM runs most often)
+    (1200, 680, 500000, 0, "slam", "K=0 (RGB-D only, every gradient)"),
+    (1200, 680, 500000, 26, "slam", "tracking iteration (geometry-only backward: gradients for the means alone)"),
     (1200, 680, 500000, 26, "aniso", "anisotropic"),
     (1200, 680, 500000, 74, "slam", "K=74 (ScanNet large tree)"),
     (1200, 680, 500000, 102, "slam", "K=102 (Replica flat labels)"),
@@ -594,10 +598,10 @@ def main():
             import diff_gaussian_rasterization as dgr
             for (w_, h_, p_, k_, kind_, tag) in EXTRA_WORKLOADS:
                 ahead = "non-blocking" in tag
-                if (w_, h_, p_, k_, kind_) == (W, H, P, K, args.kind) and not ahead:
+                if (w_, h_, p_, k_, kind_) == (W, H, P, K, args.kind) and not ahead and "geometry-only" not in tag:
                     continue
                 wl.release()
-                wl = Workload(dev, w_, h_, p_, k_, kind_, 0, 1)
+                wl = Workload(dev, w_, h_, p_, k_, kind_, 0, 1, geo=("geometry-only" in tag))
                 dgr.set_async_forward(ahead)
                 try:
                     # small workloads take a fraction of a millisecond per step: enough steps for ~50 ms of timed region, and the better

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
     __shared__ float s_medj[BATCH];                    // median-depth gradient of each staged splat: see "median" below
     __shared__ uint8_t s_segtab[4][Q_ROWS][4];         // segment of each (row, group) pair of the chunk, Q_SEG_ZERO where the group does not visit the row
 
-    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    const int tile = HSR_TILE_OF_BLOCK(blockIdx.x, (a.W + HSR_TILE_X - 1) / HSR_TILE_X, (a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
     if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, gq = lane >> 4, l16 = lane & 15;
     const TileGeom tg = tile_geom_sub(tile, a.W, a.H, t);
@@ -214,21 +214,6 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
     const float ntfbg = -T_final * (a.bg[0] * dpx0 + a.bg[1] * dpx1 + a.bg[2] * dpx2);   // the background term of dL/dalpha, x 1 / (1 - alpha)
     const float kx2 = (a.W) / HSR_LOG2E, ky2 = (a.H) / HSR_LOG2E;                        // 2 kx, 2 ky of hsr_render_bwd_sub.hip
     float Racc = 0.f;   // the reference's accum_rec AFTER the last accepted splat (backward.cu:630-640, h = colour . dL_dpixel)
-    // centre of this lane's sub-block
-    const float cxg = pfx - (float)(l16 & 3) + 1.5f, cyg = pfy - (float)(l16 >> 2) + 1.5f;
-
-    // packed-row columns of the accumulator columns this lane holds (col = lane & 15 of channel group g), or -1; compact rows: columns
-    // below 16 leave through the emission table (slot = column - 7)
-    int colg[NGA], tslot[NGA];
-#pragma unroll
-    for (int g = 0; g < NGA; g++) {
-        const int ch = 16 * g + l16;                                                        // MFMA column: sem 0..KC-1, r, g, b, depth, opacity
-        const int chl = ch < KC ? (ch < a.K ? ch : -1) : (ch < KC + 5 ? a.K + (ch - KC) : -1);   // the row's channel column, or none
-        const int col = (GEO || chl < 0) ? -1 : hsr_grow_col(CL ? 1 : 0, a.K, chl);
-        colg[g] = col >= 16 ? col : -1;
-        tslot[g] = (CL && col >= 7 && col < 16) ? col - 7 : -1;
-    }
-
     char* const panb = reinterpret_cast<char*>(&s_pan[0][0]);
     const char* const entb = reinterpret_cast<const char*>(&s_ent[0]);
     // Panel layout.  K > 0 / K = 0: a W panel and a Q panel of Q_NSEG segments of 17 words (16 pixels + 1).  GEO: ONE panel of segments of
@@ -269,6 +254,21 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
     auto flush = [&](int nrows) {
         wave_lds_fence();
         const uint32_t st = *reinterpret_cast<const uint32_t*>(&s_segtab[wv][l16][0]);   // row l16: the segments of its four groups
+        // (per-lane constants of the flush, recomputed here rather than kept live through the visit loop: registers)
+        // centre of this lane's sub-block
+        const float cxg = pfx - (float)(l16 & 3) + 1.5f, cyg = pfy - (float)(l16 >> 2) + 1.5f;
+        // packed-row columns of the accumulator columns this lane holds (col = lane & 15 of channel group g), or -1; compact rows: columns
+        // below 16 leave through the emission table (slot = column - 7)
+        constexpr bool ALL_IN_LINE0 = CL && NCH <= 9;   // K <= 4 with compact rows: every channel sum rides in line 0, no atomics of their own
+        int colg[NGA], tslot[NGA];
+#pragma unroll
+        for (int g = 0; g < NGA; g++) {
+            const int ch = 16 * g + l16;                                                        // MFMA column: sem 0..KC-1, r, g, b, depth, opacity
+            const int chl = ch < KC ? (ch < a.K ? ch : -1) : (ch < KC + 5 ? a.K + (ch - KC) : -1);   // the row's channel column, or none
+            const int col = (GEO || chl < 0) ? -1 : hsr_grow_col(CL ? 1 : 0, a.K, chl);
+            colg[g] = (col >= 16 && !ALL_IN_LINE0) ? col : -1;
+            tslot[g] = (CL && col >= 7 && col < 16) ? col - 7 : -1;
+        }
         // (1) D[16 entries][16 NG channels] = W . G: lane (row l16, k-slice gq) reads pixel 4 m + gq, i.e. word 4 (m & 3) + gq of the
         //     row's segment of group m >> 2 (the zero segment where that group does not visit the row)
         f32x4 acc[NGA];
@@ -285,12 +285,23 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
             }
             asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
             asm volatile("" : "+v"(av[8]), "+v"(av[9]), "+v"(av[10]), "+v"(av[11]), "+v"(av[12]), "+v"(av[13]), "+v"(av[14]), "+v"(av[15]));
+            if (NG == 1) {
+                // one column group: two accumulation chains (even / odd k-steps) so that a matrix instruction does not wait for the one before
+                f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int m = 0; m < 16; m++)
+                for (int m = 0; m < 16; m += 2) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], Breg[0][m], acc[0], 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m + 1], Breg[0][m + 1], acc2, 0, 0, 0);
+                }
+                acc[0] += acc2;
+            } else {
 #pragma unroll
-                for (int g = 0; g < NG; g++)
-                    if (!QAB(a, 64)) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], Breg[g][m], acc[g], 0, 0, 0);
-                    else acc[g][0] += av[m] * Breg[g][m];
+                for (int m = 0; m < 16; m++)
+#pragma unroll
+                    for (int g = 0; g < NG; g++)
+                        if (!QAB(a, 64)) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], Breg[g][m], acc[g], 0, 0, 0);
+                        else acc[g][0] += av[m] * Breg[g][m];
+            }
         }
         // (2) lane (row l16, group gq): the six moments of the group's 16 gda values of that row about the sub-block centre.
         //     pixel 4 yy + xx of the group sits at (u, v) = (xx - 1.5, yy - 1.5)
@@ -359,7 +370,7 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
             o[6] = s6;
         }
         // D[row = 4*(lane>>4) + r][col = lane&15]: one atomic wave-instruction per register = 4 rows x 64 bytes
-        if (!GEO) {
+        if (!GEO && !ALL_IN_LINE0) {
             const uint4 b4 = *reinterpret_cast<const uint4*>(&s_cid[wv][4 * (lane >> 4)]);   // the four row offsets in one LDS read
             const uint32_t bb[4] = {b4.x, b4.y, b4.z, b4.w};
             const int nr = nrows - 4 * (lane >> 4);   // how many of this lane's four rows exist
@@ -387,29 +398,50 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
 #pragma unroll
         for (int vi = 0; vi < 7; vi++) tb[l16 * Q_TB + 4 * vi + gq] = o[vi];
         wave_lds_fence();
+        // Emission of line 0.  Every LDS read of every pass is issued first and unconditionally (clamped indices), the atomics follow: left to
+        // itself hipcc sinks each read into the branch that uses it and the passes become a chain of a dozen exposed LDS round trips
+        // (the K = 0 flush took 3 800 cycles per chunk against 1 650 for the geometry-only one: profiles/r04_h_trace_k0.txt).
         if (CL && !GEO) {
-            // line 0, columns 0..15: four wave-instructions of 4 rows x 16 values, each row's line ONE request
+            // columns 0..15: four wave-instructions of 4 rows x 16 values, each row's line ONE request
             const int nl0 = hsr_grow_nl0(a.K);
+            const int vi = lane & 15;
+            float4 sa[4];
+            float ta[4];
+            uint32_t cid[4];
 #pragma unroll
             for (int pass = 0; pass < 4; pass++) {
-                const int row = (lane >> 4) + 4 * pass, vi = lane & 15;
-                const float4 sa = *reinterpret_cast<const float4*>(tb + row * Q_TB + (vi & 7) * 4);
-                const float ta = pq[row * 12 + min(max(vi - 7, 0), 11)];
-                const float val = vi < 7 ? (sa.x + sa.y) + (sa.z + sa.w) : ta;
-                const uint32_t base = s_cid[wv][row] + (uint32_t)vi;
+                const int row = (lane >> 4) + 4 * pass;
+                sa[pass] = *reinterpret_cast<const float4*>(tb + row * Q_TB + (vi & 7) * 4);
+                ta[pass] = pq[row * 12 + min(max(vi - 7, 0), 11)];
+                cid[pass] = s_cid[wv][row];
+            }
+            asm volatile("" : "+v"(sa[0].x), "+v"(sa[1].x), "+v"(sa[2].x), "+v"(sa[3].x), "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2]), "+v"(ta[3]),
+                         "+v"(cid[0]), "+v"(cid[1]), "+v"(cid[2]), "+v"(cid[3]));
+#pragma unroll
+            for (int pass = 0; pass < 4; pass++) {
+                const int row = (lane >> 4) + 4 * pass;
+                const float val = vi < 7 ? (sa[pass].x + sa[pass].y) + (sa[pass].z + sa[pass].w) : ta[pass];
                 if (vi < 7 + nl0 && row < nrows && val != 0.f && !(a.debug_flags & 1))
-                    atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(a.grow) + 4u * base), val);
+                    atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(a.grow) + 4u * (cid[pass] + (uint32_t)vi)), val);
             }
         } else {
             // columns 0..6: two wave-instructions of 8 rows x 7 values, so that each row's line is ONE request
+            const int vi = lane & 7;
+            float4 sa[2];
+            uint32_t cid[2];
 #pragma unroll
             for (int pass = 0; pass < 2; pass++) {
-                const int row = (lane >> 3) + 8 * pass, vi = lane & 7;
-                const float4 sa = *reinterpret_cast<const float4*>(tb + row * Q_TB + vi * 4);
-                const float val = (sa.x + sa.y) + (sa.z + sa.w);
-                const uint32_t base = s_cid[wv][row] + (uint32_t)vi;
+                const int row = (lane >> 3) + 8 * pass;
+                sa[pass] = *reinterpret_cast<const float4*>(tb + row * Q_TB + vi * 4);
+                cid[pass] = s_cid[wv][row];
+            }
+            asm volatile("" : "+v"(sa[0].x), "+v"(sa[1].x), "+v"(cid[0]), "+v"(cid[1]));
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                const int row = (lane >> 3) + 8 * pass;
+                const float val = (sa[pass].x + sa[pass].y) + (sa[pass].z + sa[pass].w);
                 if (vi < 7 && row < nrows && val != 0.f && !(a.debug_flags & 1))
-                    atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(a.grow) + 4u * base), val);
+                    atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(a.grow) + 4u * (cid[pass] + (uint32_t)vi)), val);
             }
         }
         wave_lds_fence();
@@ -612,8 +644,7 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
 // packed mode, K <= 27, P * grow_stride < 2^30 (32-bit row addressing): the caller checks.  a.grow_layout: hsr_backward_row_layout.
 int hsr_launch_render_backward_q(const RenderBwdArgs& a, hipStream_t stream)
 {
-    const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    const dim3 grid(hsr_tile_grid(tiles)), block(256);
+    const dim3 grid(HSR_GRID_OF_TILES((a.W + HSR_TILE_X - 1) / HSR_TILE_X, (a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)), block(256);
     const int K = a.semantic ? a.K : 0;
     const bool cl = a.grow_layout == 1;
     if (K == 0) {
@@ -632,7 +663,6 @@ int hsr_launch_render_backward_q(const RenderBwdArgs& a, hipStream_t stream)
 // geometry-only gradients (a.grow_stride == 16): any K
 int hsr_launch_render_backward_qgeo(const RenderBwdArgs& a, hipStream_t stream)
 {
-    const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    render_bwd_q_kernel<0, 208, true><<<dim3(hsr_tile_grid(tiles)), dim3(256), 0, stream>>>(a);
+    render_bwd_q_kernel<0, 208, true><<<dim3(HSR_GRID_OF_TILES((a.W + HSR_TILE_X - 1) / HSR_TILE_X, (a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)), dim3(256), 0, stream>>>(a);
     return HSR_OK;
 }

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
     __shared__ uint8_t s_subcnt[4][16];
     __shared__ int s_wdone[4];
 
-    const int tile = hsr_block_tile(blockIdx.x, ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y));
+    const int tile = HSR_TILE_OF_BLOCK(blockIdx.x, (a.W + HSR_TILE_X - 1) / HSR_TILE_X, (a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
     if (tile >= ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)) return;
     const int t = threadIdx.x, wv = t >> 6;
     if (a.bin.base) {   // speculative forward: the list lives where num_rendered says
@@ -616,8 +616,7 @@ __global__ void __launch_bounds__(256, (SUB && KC <= 26) ? (KC == 16 ? 5 : 4) : 
 
 int hsr_launch_render_forward(const RenderFwdArgs& a, hipStream_t stream)
 {
-    const int tiles = ((a.W + HSR_TILE_X - 1) / HSR_TILE_X) * ((a.H + HSR_TILE_Y - 1) / HSR_TILE_Y);
-    const dim3 grid(hsr_tile_grid(tiles)), block(256);
+    const dim3 grid(HSR_GRID_OF_TILES((a.W + HSR_TILE_X - 1) / HSR_TILE_X, (a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)), block(256);
     // Default for K <= 28: the per-lane kernel on 4x4 sub-block lists (SUB).  Measured at the headline workload (500k
     // Gaussians, 1200x680, K = 26): 0.18 ms against 0.22 ms for the same kernel on quadrant lists (HSR_FWD_IMPL=valu, kept
     // in the ablate build for A/B timing) and 0.27 ms for round 1's pair-pipelined matrix-core kernel (EXPERIMENTS.md §4: the ~25 VALU

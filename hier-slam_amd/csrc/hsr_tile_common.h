@@ -31,6 +31,25 @@
 // same time and share those lines.  Launch hsr_tile_grid(T) workgroups; workgroups mapped past T exit at once.
 __host__ __device__ inline int hsr_tile_grid(int T) { return 8 * ((T + 7) / 8); }
 __device__ __forceinline__ int hsr_block_tile(int b, int T) { return (b & 7) * ((T + 7) >> 3) + (b >> 3); }
+// Experiment ("the untried 2-D XCD -> region tile mapping"; -DHSR_TILE_MAP_2D, tools/r04_map2d_ab.sh): each XCD gets a
+// RECTANGLE of the tile grid (4 x 2 regions) and walks it row by row, so that the ~128 workgroups an XCD has in flight cover a compact
+// patch (about 7 rows of 19 tiles at 1200 x 680) instead of 1.7 rows of the whole image width: splats that span two tile rows find their
+// record and feature row in this XCD's L2 more often.  Workgroups mapped outside the grid exit at once.
+__host__ __device__ inline int hsr_tile_grid_2d(int tx, int ty) { return 8 * (((tx + 3) / 4) * ((ty + 1) / 2)); }
+__device__ __forceinline__ int hsr_block_tile_2d(int b, int tx, int ty)
+{
+    const int rw = (tx + 3) / 4, rh = (ty + 1) / 2;     // region size in tiles
+    const int x = b & 7, i = b >> 3;
+    const int cx = (x & 3) * rw + i % rw, cy = (x >> 2) * rh + i / rw;
+    return (cx < tx && cy < ty) ? cy * tx + cx : tx * ty;   // tx * ty: "past the grid"
+}
+#ifdef HSR_TILE_MAP_2D
+#define HSR_TILE_OF_BLOCK(b, tx, ty) hsr_block_tile_2d((b), (tx), (ty))
+#define HSR_GRID_OF_TILES(tx, ty) hsr_tile_grid_2d((tx), (ty))
+#else
+#define HSR_TILE_OF_BLOCK(b, tx, ty) hsr_block_tile((b), (tx) * (ty))
+#define HSR_GRID_OF_TILES(tx, ty) hsr_tile_grid((tx) * (ty))
+#endif
 
 // The speculative forward found its binning buffer too small for num_rendered (hsr_bin_resolve failed): nothing can be rendered.  A
 // blocking hsr_forward* call runs the kernels again with a grown buffer; a NON-blocking one (hsr_forward_arm_async) cannot, so the tile

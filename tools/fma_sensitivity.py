@@ -30,12 +30,19 @@ GOLDEN = {  # tests/golden/make_golden.py
 SMALL = {"small 256x256 P=5000 K=26 (BASELINE configs[0] size)": (256, 256, 5000, 26, "slam", 2.0, True, (0.0, 0.0, 0.0), 3, 0.0)}
 
 
-def bench_scene(W, H, P, K, kind):
-    """the scene bench.py times (same generator, seeds and camera)"""
+def bench_scene(W, H, P, K, kind, rank=0):
+    """the scene bench.py times (same generator, seeds and camera); rank > 0: the camera of that rank's keyframe in the multi-GPU bench
+    (a small rotation + translation: with the identity camera of rank 0 the view transform multiplies by 0 and 1 only and the depth
+    key bits cannot move)"""
     from hsr_utils.camera import replica_intrinsics, setup_camera_tensors
     from hsr_utils.synthetic import make_scene, make_upstream_grads
     k = replica_intrinsics(W, H)
-    cam = setup_camera_tensors(W, H, k, np.eye(4))
+    w2c = np.eye(4)
+    if rank:
+        a = 0.01 * rank
+        w2c[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        w2c[:3, 3] = [0.01 * rank, -0.005 * rank, 0.0]
+    cam = setup_camera_tensors(W, H, k, w2c)
     sc = make_scene(P, W, H, K, k, seed=0, kind=kind)
     up = make_upstream_grads(W, H, K, seed=1)
     up = {n: v * float(W * H) for n, v in up.items()}
@@ -115,7 +122,7 @@ def compare(name, cam, sc, up, semantic, threads=0, with_backward=True):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--scenes", nargs="+", default=["goldens", "small"], choices=["goldens", "small", "headline", "stress"])
+    ap.add_argument("--scenes", nargs="+", default=["goldens", "small"], choices=["goldens", "small", "headline", "headline_tilted", "stress"])
     ap.add_argument("--json", default=None)
     ap.add_argument("--threads", type=int, default=0)
     args = ap.parse_args()
@@ -132,6 +139,10 @@ def main():
     if "headline" in args.scenes:
         cam, sc, up = bench_scene(1200, 680, 500000, 26, "slam")
         out.append(compare("headline 1200x680 P=500000 K=26 (bench.py scene)", cam, sc, up, True, args.threads))
+        print(json.dumps(out[-1]), flush=True)
+    if "headline_tilted" in args.scenes:
+        cam, sc, up = bench_scene(1200, 680, 500000, 26, "slam", rank=3)
+        out.append(compare("headline size, camera of rank 3's keyframe (rotated 0.03 rad, translated)", cam, sc, up, True, args.threads))
         print(json.dumps(out[-1]), flush=True)
     if "stress" in args.scenes:
         cam, sc, up = bench_scene(1920, 1080, 2000000, 74, "slam")

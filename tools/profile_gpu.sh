@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --no-workloads $ARGS > $OUT/trace.log 2>&1
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_F32" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_F32" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_IFETCH"; do
   n=$(echo "$set" | cut -d' ' -f1)
   timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$n -- python bench.py --no-workloads $ARGS > $OUT/pmc_$n.log 2>&1 || echo "pmc pass $n failed"
 done
