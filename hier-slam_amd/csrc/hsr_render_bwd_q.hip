@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
         wave_lds_fence();
         // Emission of line 0.  Every LDS read of every pass is issued first and unconditionally (clamped indices), the atomics follow: left to
         // itself hipcc sinks each read into the branch that uses it and the passes become a chain of a dozen exposed LDS round trips
-        // (the K = 0 flush took 3 800 cycles per chunk against 1 650 for the geometry-only one: profiles/r04_h_trace_k0.txt).
+        // (the K = 0 flush took 3 800 cycles per chunk against 1 650 for the geometry-only one: profiles/r04_k_trace_bwd.txt and the A/B of EXPERIMENTS.md §10a).
         if (CL && !GEO) {
             // columns 0..15: four wave-instructions of 4 rows x 16 values, each row's line ONE request
             const int nl0 = hsr_grow_nl0(a.K);

@@ -15,7 +15,7 @@ def main(src, P=500000, W=1200, H=680, K=26, kind="slam"):
     d = json.load(open(src))
     pmc, ker = d["pmc"], d["kernels"]
     find = lambda sub: next((k for k in pmc if sub in k), None)
-    names = {"fwd_render": find("render_fwd_kernel<%d" % K), "bwd_render": find("render_bwd_sub_kernel<%d" % K) or find("render_bwd_subw_kernel"),
+    names = {"fwd_render": find("render_fwd_kernel<%d" % K), "bwd_render": find("render_bwd_q_kernel<%d" % K) or find("render_bwd_sub_kernel<%d" % K) or find("render_bwd_subw_kernel"),
              "fwd_preprocess": find("preprocess_kernel"), "bwd_preprocess": find("preprocess_backward_kernel")}
     out = {"workload": {"P": P, "width": W, "height": H, "K": K, "kind": kind},
            "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_gpu.sh)" % os.path.relpath(src, ROOT),
