@@ -63,6 +63,18 @@ int backward_mode()
 }
 bool rows_mode_requested() { return backward_mode() == 1; }
 
+// semantic -> alpha gradient: 0 as the reference computes it (none: backward.cu:834-845 reads a scratch nothing wrote), 1 exact
+// (opt-in; HSR_SEMANTIC_ALPHA=exact or hsr_set_semantic_alpha_mode)
+int g_sem_alpha_mode = -1;
+int semantic_alpha_mode()
+{
+    if (g_sem_alpha_mode < 0) {
+        const char* e = getenv("HSR_SEMANTIC_ALPHA");
+        g_sem_alpha_mode = (e && !strcmp(e, "exact")) ? 1 : 0;
+    }
+    return g_sem_alpha_mode;
+}
+
 int acquire(hsr_buffer* b, size_t need, const char* what, char** out)
 {
     if (!b) {
@@ -641,6 +653,19 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
         hsr_set_error("dL_dconic and dL_ddepth may only be NULL when a scratch buffer carries the accumulation (packed / rows mode)");
         return HSR_ERR_INVALID_ARGUMENT;
     }
+    // opt-in exact semantic -> alpha term: extra passes over the packed rows (a geometry-only caller that passes no dL_dpix_sem has no
+    // semantic loss: nothing to add)
+    const bool sem_alpha = semantic_alpha_mode() == 1 && K > 0 && in.dL_dpix_sem != nullptr;
+    if (sem_alpha) {
+        if (!use_packed || (size_t)P * (size_t)(geo ? 16 : hsr_grow_stride(K)) >= ((size_t)1 << 30)) {
+            hsr_set_error("the exact semantic -> alpha mode needs the packed accumulation mode (a scratch buffer of hsr_backward_scratch_bytes) and P * row stride < 2^30");
+            return HSR_ERR_INVALID_ARGUMENT;
+        }
+        if (!in.semantics) {
+            hsr_set_error("the exact semantic -> alpha mode reads semantics_precomp, which is NULL");
+            return HSR_ERR_INVALID_ARGUMENT;
+        }
+    }
     float* grow = nullptr;
     int rows_kc = 0;
     float* rows = nullptr;
@@ -706,6 +731,10 @@ int backward_impl(const BwdIn& in, hipStream_t stream)
             else hsr_launch_render_backward_qgeo(ra, stream);
         } else {
             hsr_launch_render_backward(ra, stream);
+        }
+        if (sem_alpha) {
+            ra.semantics = in.semantics;
+            hsr_launch_render_backward_qsema(ra, stream);
         }
     }
     HSR_LAUNCH_CHECK(in.debug, stream);
@@ -829,6 +858,18 @@ int hsr_set_backward_mode(int mode)
     }
 #endif
     g_bwd_mode = mode;
+    return HSR_OK;
+}
+
+int hsr_get_semantic_alpha_mode(void) { return semantic_alpha_mode(); }
+
+int hsr_set_semantic_alpha_mode(int mode)
+{
+    if (mode != 0 && mode != 1) {
+        hsr_set_error("semantic alpha mode must be 0 (as the reference: no semantic -> alpha gradient) or 1 (exact)");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    g_sem_alpha_mode = mode;
     return HSR_OK;
 }
 

@@ -210,6 +210,8 @@ struct RenderBwdArgs {
     float* grow;          // packed mode: [P][grow_stride] one gradient row per Gaussian (scratch), else NULL
     int grow_stride;
     int grow_layout;      // 0: classic packed row; 1: compact (hsr_tile_common.h, hsr_grow_col) — hsr_render_bwd_q.hip only
+    const float* semantics = nullptr;   // [P,K] features: read by the exact semantic -> alpha passes only (hsr_launch_render_backward_qsema)
+    int sem_c0 = 0;                      // ... first channel of the pass
 };
 int hsr_launch_render_backward(const RenderBwdArgs& a, hipStream_t stream);
 int hsr_launch_render_backward_mfma(const RenderBwdArgs& a, hipStream_t stream);
@@ -218,6 +220,7 @@ int hsr_launch_render_backward_sub(const RenderBwdArgs& a, hipStream_t stream); 
 int hsr_launch_render_backward_geo(const RenderBwdArgs& a, hipStream_t stream);   // packed mode, geometry gradients only (grow_stride 16)
 int hsr_launch_render_backward_q(const RenderBwdArgs& a, hipStream_t stream);     // K <= 27, packed mode: round 4, both per-pixel factors in LDS panels, moments per chunk
 int hsr_launch_render_backward_qgeo(const RenderBwdArgs& a, hipStream_t stream);  // geometry gradients only, same scheme
+int hsr_launch_render_backward_qsema(const RenderBwdArgs& a, hipStream_t stream); // packed rows: + the exact semantic -> alpha term into columns 0..5 (opt-in)
 int hsr_backward_row_layout(int K_semantic, bool packed, int P);   // layout hsr_launch_render_backward will expect for this K (0 unless it takes the Q-panel kernel and the compact row saves a line)
 int hsr_launch_render_backward_subw(const RenderBwdArgs& a, hipStream_t stream);  // K > 27, packed mode: sub-block masks, channel passes
 int hsr_launch_render_backward_wide(const RenderBwdArgs& a, hipStream_t stream);  // semantic, K > 27: matrix-core channel passes

@@ -108,16 +108,24 @@ static_assert(Q_ROWS * Q_TB <= Q_SEG_ZERO * Q_SEGW, "the emission table overlays
 // Four workgroups per CU (128 registers) where the B operand is one column group or none; with two column groups (32 registers of B
 // operand) the kernel would spill at 128 registers, and its time is set by the gradient atomics anyway (three lines per row): three.
 // CL: compact rows (hsr_tile_common.h, hsr_grow_col): the last min(9, K + 5) channel columns leave through line 0 together with columns 0..6.
-template <int KC, int BATCH, bool GEO, bool CL = false>
-__global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd_q_kernel(RenderBwdArgs a)
+// SEMA (with GEO): the opt-in "exact" semantic -> alpha pass (hsr_set_semantic_alpha_mode; the reference's backward.cu:834-845 reads an
+// unwritten scratch there, so its semantic loss never reaches alpha — DESIGN.md §9).  The term is linear in dL/dalpha, so it is its own
+// pass over the same lists: h := sum over channels [a.sem_c0, a.sem_c0 + KC) of feature(splat) * dL_dpixel_semantic(pixel) in place of
+// the colour / depth / opacity dot product, no background term, no median, no direct sums; its moments land in columns 0..5 of the rows
+// the main pass fills (a.grow_stride is the main pass's).  The splat's KC features ride behind the 48-byte record.
+template <int KC, int BATCH, bool GEO, bool CL = false, bool SEMA = false>
+__global__ void __launch_bounds__(256, (SEMA || (!GEO && KC + 5 > 16)) ? 3 : 4) render_bwd_q_kernel(RenderBwdArgs a)
 {
+    static_assert(!SEMA || (GEO && KC % 4 == 0 && KC > 0), "the semantic -> alpha pass is a geometry-only pass over whole float4s of features");
+    constexpr int ENTB = SEMA ? Q_ENTB + 4 * KC : Q_ENTB;   // bytes per staged record
+    constexpr int REC4 = ENTB / 16;
     constexpr int NCH = GEO ? 0 : KC + 5;          // sem[KC], r, g, b, depth, opacity(direct)
     constexpr int NG = GEO ? 0 : (NCH + 15) / 16;  // 16-channel groups
     constexpr int NGA = NG > 0 ? NG : 1;
     static_assert(NG <= 2, "at most 32 direct channels per launch");
-    static_assert(BATCH <= 256 && (BATCH + 1) * Q_ENTB < 65536, "batch slots are bytes, record offsets 16 bits");
+    static_assert(BATCH <= 256 && (BATCH + 1) * ENTB < 65536, "batch slots are bytes, record offsets 16 bits");
     // one 48-byte record per staged splat { x, y, A', B' | r, g, b, depth | C', opacity, B'/2, - }; record BATCH is the dummy
-    __shared__ float4 s_ent[3 * (BATCH + 1)];
+    __shared__ float4 s_ent[REC4 * (BATCH + 1)];
     __shared__ int s_id[BATCH];
     __shared__ uint16_t s_mask[BATCH + 2];             // sub-block mask of each staged splat
     __shared__ uint8_t s_list[4][256];
@@ -148,7 +156,7 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
     const long long tr_t0 = TR_NOW();
     (void)tr_stage; (void)tr_loop; (void)tr_flush; (void)tr_iters; (void)tr_chunks; (void)tr_accepted; (void)tr_t0;
 
-    if (t < 3) s_ent[3 * BATCH + t] = make_float4(0.f, 0.f, 0.f, 0.f);   // the dummy record: opacity 0 -> alpha 0 -> never active
+    if (t < REC4) s_ent[REC4 * BATCH + t] = make_float4(0.f, 0.f, 0.f, 0.f);   // the dummy record: opacity 0 -> alpha 0 -> never active
 
     // every prologue load unconditional and issued before anything consumes one
     const size_t pix_ld = inside ? pix_id : 0;
@@ -160,7 +168,12 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
     float dpd = a.dL_dpix_depth[pix_ld], dpm = a.dL_dpix_median[pix_ld], dpo = a.dL_dpix_opacity[pix_ld];
     float semv[KC > 0 ? KC : 1];
 #pragma unroll
-    for (int c = 0; c < KC; c++) semv[c] = a.dL_dpix_sem[(size_t)min(c, a.K - 1) * N + pix_ld];
+    for (int c = 0; c < KC; c++) semv[c] = a.dL_dpix_sem[(size_t)min((SEMA ? a.sem_c0 : 0) + c, a.K - 1) * N + pix_ld];
+    if (SEMA) {
+#pragma unroll
+        for (int c = 0; c < KC; c++) semv[c] = (a.sem_c0 + c < a.K) ? semv[c] * inm : 0.f;
+        dpx0 = dpx1 = dpx2 = dpd = dpm = dpo = 0.f;   // nothing but the semantic term in this pass
+    }
     dpx0 *= inm; dpx1 *= inm; dpx2 *= inm; dpd *= inm; dpm *= inm; dpo *= inm;
     const float T_final = T_final_ld * inm;
     float T = T_final;
@@ -221,7 +234,7 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
     constexpr uint32_t SEGB = GEO ? 2 * Q_SEGB : Q_SEGB;                     // bytes per segment
     const uint32_t wave_off = (uint32_t)(wv * 2 * Q_PANEL * 4);              // byte offset of the wave's panels in s_pan
     const uint32_t lane16_off = wave_off + (uint32_t)(l16 * (GEO ? 8 : 4));  // ... of this lane's pixel in segment 0
-    const uint2 DUMMY_ELEM = make_uint2((uint32_t)(BATCH * Q_ENTB), (uint32_t)Q_SEG_DUMMY * SEGB);
+    const uint2 DUMMY_ELEM = make_uint2((uint32_t)(BATCH * ENTB), (uint32_t)Q_SEG_DUMMY * SEGB);
     uint2* const ordp = &s_ord[wv][gq][0];
 
     // ---- software-pipelined staging ----
@@ -326,7 +339,7 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
             }
             const uint32_t eo = s_rowent[wv][l16];
             // median: whatever has been added for this row's splat so far, by any wave — taken (exchanged with zero), so that it is emitted once
-            if (gq == 0 && eo < (uint32_t)(BATCH * Q_ENTB)) medsum = atomicExch(&s_medj[eo / Q_ENTB], 0.f);
+            if (!SEMA && gq == 0 && eo < (uint32_t)(BATCH * ENTB)) medsum = atomicExch(&s_medj[eo / ENTB], 0.f);
             const float4* ent = reinterpret_cast<const float4*>(entb + eo);
             const float4 e0 = ent[0], e2 = ent[2];
             float s0[4], s1[4], s2[4];
@@ -450,7 +463,7 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
     for (int hi = hi_all; hi > 0; hi -= BATCH) {
         const int cnt = min(BATCH, hi);
         // list position of batch slot j is hi - 1 - j: "behind the last contributor" and "the median splat" as record-offset tests, per batch
-        const int jf_off = (hi - last_contributor) * Q_ENTB;
+        const int jf_off = (hi - last_contributor) * ENTB;
         const long long ts = TR_NOW();
         (void)ts;
         __syncthreads();
@@ -461,9 +474,22 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
             s_mask[t] = (uint16_t)mask;
             s_id[t] = id_cur;
             s_medj[t] = 0.f;
-            s_ent[3 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
-            s_ent[3 * t + 1] = make_float4(p_r, p_g, p_b, p_d);
-            s_ent[3 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, (-0.5f * HSR_LOG2E) * p_co.y, 0.f);   // C', opacity, B' / 2
+            s_ent[REC4 * t] = make_float4(p_xy.x, p_xy.y, (-0.5f * HSR_LOG2E) * p_co.x, -HSR_LOG2E * p_co.y);
+            s_ent[REC4 * t + 1] = make_float4(p_r, p_g, p_b, p_d);
+            s_ent[REC4 * t + 2] = make_float4((-0.5f * HSR_LOG2E) * p_co.z, p_co.w, (-0.5f * HSR_LOG2E) * p_co.y, 0.f);   // C', opacity, B' / 2
+            if (SEMA) {   // the splat's features of this pass's channels (zero past K); read here, once per staged splat
+                const float* f = a.semantics + (size_t)id_cur * (size_t)a.K;
+#pragma unroll
+                for (int q = 0; q < KC / 4; q++) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int ch = a.sem_c0 + 4 * q + i;
+                        v[i] = ch < a.K ? f[ch] : 0.f;
+                    }
+                    s_ent[REC4 * t + 3 + q] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
         }
         publish_quadrant_lists(qmask, t, s_list, s_lcnt);
         __syncthreads();
@@ -507,7 +533,7 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
                 touch = touch && l16 < nrows;
                 ball = __ballot(touch);
             }
-            const uint32_t eoff = (uint32_t)(l16 < nrows ? jr : BATCH) * (uint32_t)Q_ENTB;
+            const uint32_t eoff = (uint32_t)(l16 < nrows ? jr : BATCH) * (uint32_t)ENTB;
             if (gq == 0) {
                 s_rowent[wv][l16] = eoff;
                 s_cid[wv][l16] = (uint32_t)s_id[min(jr, BATCH - 1)] * (uint32_t)a.grow_stride;   // once per chunk row, not once per emitted register
@@ -553,7 +579,19 @@ __global__ void __launch_bounds__(256, (!GEO && KC + 5 > 16) ? 3 : 4) render_bwd
                 o.Gm = active ? G : 0.f;
                 o.inv = QAB(a, 1024) ? 1.0f + o.am : __builtin_amdgcn_rcpf(1.0f - o.am);   // 1 where the pixel skips the splat: T * 1 = T
                 o.nb = ntfbg * o.inv;
-                o.h = fmaf(rb.x, dpx0, fmaf(rb.y, dpx1, fmaf(rb.z, dpx2, fmaf(rb.w, dpd, dpo))));
+                if (SEMA) {
+                    const float4* f = reinterpret_cast<const float4*>(entb + e.x + Q_ENTB);
+                    float h0 = 0.f, h1 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < KC / 4; q++) {
+                        const float4 v = f[q];
+                        h0 = fmaf(v.x, semv[SEMA ? 4 * q : 0], fmaf(v.y, semv[SEMA ? 4 * q + 1 : 0], h0));
+                        h1 = fmaf(v.z, semv[SEMA ? 4 * q + 2 : 0], fmaf(v.w, semv[SEMA ? 4 * q + 3 : 0], h1));
+                    }
+                    o.h = h0 + h1;
+                } else {
+                    o.h = fmaf(rb.x, dpx0, fmaf(rb.y, dpx1, fmaf(rb.z, dpx2, fmaf(rb.w, dpd, dpo))));
+                }
                 return o;
             };
             auto stage_b = [&](const StageA& c) {
@@ -657,6 +695,19 @@ int hsr_launch_render_backward_q(const RenderBwdArgs& a, hipStream_t stream)
     else if (K == 26 && !cl) render_bwd_q_kernel<26, 224, false, false><<<grid, block, 0, stream>>>(a);
     else if (cl) render_bwd_q_kernel<27, 224, false, true><<<grid, block, 0, stream>>>(a);
     else render_bwd_q_kernel<27, 224, false, false><<<grid, block, 0, stream>>>(a);
+    return HSR_OK;
+}
+
+// The exact semantic -> alpha term (opt-in, hsr_set_semantic_alpha_mode(1)): AFTER the main pass has been enqueued on the same stream,
+// ceil(K / 16) passes of the SEMA variant add their moments into columns 0..5 of the same rows.  a.grow / a.grow_stride: the main pass's.
+int hsr_launch_render_backward_qsema(const RenderBwdArgs& a0, hipStream_t stream)
+{
+    RenderBwdArgs a = a0;
+    const dim3 grid(HSR_GRID_OF_TILES((a.W + HSR_TILE_X - 1) / HSR_TILE_X, (a.H + HSR_TILE_Y - 1) / HSR_TILE_Y)), block(256);
+    for (int c0 = 0; c0 < a.K; c0 += 16) {
+        a.sem_c0 = c0;
+        render_bwd_q_kernel<16, 208, true, false, true><<<grid, block, 0, stream>>>(a);
+    }
     return HSR_OK;
 }
 

@@ -90,6 +90,10 @@ def _load():
     lib.hsr_profile_enable.argtypes = [ci]
     lib.hsr_get_backward_mode.restype = ci
     lib.hsr_get_backward_mode.argtypes = []
+    lib.hsr_set_semantic_alpha_mode.restype = ci
+    lib.hsr_set_semantic_alpha_mode.argtypes = [ci]
+    lib.hsr_get_semantic_alpha_mode.restype = ci
+    lib.hsr_get_semantic_alpha_mode.argtypes = []
     lib.hsr_profile_host_wait_ms.restype = C.c_double
     lib.hsr_profile_host_wait_ms.argtypes = [ci]
     lib.hsr_profile_select.restype = ci
@@ -324,6 +328,20 @@ def set_backward_mode(mode):
     rc = _lib.hsr_set_backward_mode({"packed": 0, "rows": 1, "legacy": 2}[mode])
     if rc < 0:
         _fail(rc, "hsr_set_backward_mode")
+
+
+def set_semantic_alpha(mode):
+    """'reference' (default): the semantic loss never reaches alpha, as in the reference, whose backward stages the features for that
+    term into an array nothing writes (RAST/cuda_rasterizer/backward.cu:778-779, :834-845).  'exact': the term those lines intend,
+    as extra passes of the tile kernel (process-wide; needs the default packed accumulation mode).  Opt-in: not what the reference
+    trains with."""
+    rc = _lib.hsr_set_semantic_alpha_mode({"reference": 0, "exact": 1}[mode])
+    if rc < 0:
+        _fail(rc, "hsr_set_semantic_alpha_mode")
+
+
+def get_semantic_alpha():
+    return "exact" if int(_lib.hsr_get_semantic_alpha_mode()) == 1 else "reference"
 
 
 def version():

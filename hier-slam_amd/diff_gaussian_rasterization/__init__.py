@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import _C
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "GaussianRasterizer_semantic",
-           "rasterize_gaussians", "rasterize_gaussians_semantic", "set_async_forward"]
+           "rasterize_gaussians", "rasterize_gaussians_semantic", "set_async_forward", "set_semantic_alpha"]
 
 
 def set_async_forward(on):
@@ -32,6 +32,12 @@ def set_async_forward(on):
     forward — that overflow, a `prefiltered` violation — surface when the count is resolved (in the backward), not at the forward call.
     Returns the previous setting."""
     return _C.set_async_forward(on)
+
+
+def set_semantic_alpha(mode):
+    """'reference' (default) or 'exact': whether the semantic loss reaches alpha (opacity, covariance, position).  The reference's does
+    not (its backward reads an unwritten staging array there); 'exact' adds the intended term.  See _C.set_semantic_alpha."""
+    _C.set_semantic_alpha(mode)
 
 
 import threading

@@ -75,6 +75,16 @@ size_t hsr_backward_scratch_bytes(int P, int K, int num_rendered);
 int hsr_set_backward_mode(int mode);
 int hsr_get_backward_mode(void);   /* 0 packed, 2 legacy */
 
+/* Gradient of the semantic loss with respect to alpha (process-wide; default 0, or HSR_SEMANTIC_ALPHA=exact):
+ *   0 reference : none.  The reference stages the features for this term into a shared array nothing writes
+ *                 (RAST/cuda_rasterizer/backward.cu:778-779 commented out, :834-845 read it), so its semantic loss
+ *                 moves the features only, never opacity / covariance / position.  The drop-in default.
+ *   1 exact     : the term those lines intend — (feature - accum_rec) . dL_dsemantic joins dL_dalpha like the colour
+ *                 channels' — as ceil(K / 16) extra passes of the tile kernel over the packed rows.  Needs the packed
+ *                 accumulation mode (a scratch buffer) and semantics_precomp; any K.  Not what the reference trains with. */
+int hsr_set_semantic_alpha_mode(int mode);
+int hsr_get_semantic_alpha_mode(void);
+
 /* Thread-local text of the last error returned by any hsr_* call on this thread. */
 const char* hsr_last_error(void);
 /* Library / build identification, e.g. "hsr_rast 0.1 gfx950". */

@@ -242,6 +242,14 @@ static unsigned g_accum_seed = 0;
  * reference is built without fast-math: setup.py has no such flag), gfx950's v_exp_f32 / v_rcp_f32 1 ulp each.  Decisions (alpha >= 1/255
  * ...) keep using the unperturbed value: the model varies the arithmetic, not the lists. */
 static float g_exp_ulps = 0.0f;
+/* ... and the exponent's ARGUMENT the rounding of another correct fp32 formulation.  power = -0.5 (a dx^2 + c dy^2) - b dx dy is a sum of
+ * three products; each fp32 evaluation order (the reference's with nvcc's FMA contraction, the oracle's IEEE order, the HIP kernels' pre-scaled
+ * base-2 form) rounds each product and each partial sum once, i.e. errs by up to ~1.5 * 2^-24 * S with S = 0.5 (|a| dx^2 + |c| dy^2) + |b dx dy|
+ * — NOT relative to power itself: for an elongated, rotated splat the three terms cancel (S >> |power|), and exp turns the absolute error of its argument
+ * into a relative error of G of that size: dozens of ulps on a 20:1 needle, where one ulp of exp itself (above) is the smaller effect.
+ * g_arg_roundings = the coefficient (0: off); G is multiplied by 1 + u2 * g_arg_roundings * 2^-24 * S, u2 uniform in [-1, 1], hashed. */
+static float g_arg_roundings = 0.0f;
+void hsro_set_exp_argument_error(float roundings) { g_arg_roundings = roundings > 0 ? roundings : 0.0f; }
 void hsro_set_accumulation(int fp32, unsigned seed) { g_accum_fp32 = fp32 ? 1 : 0; g_accum_seed = seed; }
 void hsro_set_exp_error(float ulps) { g_exp_ulps = ulps > 0 ? ulps : 0.0f; }
 void hsro_set_median_rule(int rule) { g_median_rule = rule ? 1 : 0; }
@@ -486,8 +494,8 @@ HsroState* hsro_forward(int P, int D, int M, int K, const float* background, int
     for (long tile = 0; tile < (long)Tn; tile++) {
         const uint32_t ty = (uint32_t)(tile / gx), tx = (uint32_t)(tile % gx);
         const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
-        real* Sacc = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
-        real* Salt = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
+        real* Sacc = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? 3 * K : 1));
+        real* Salt = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? 3 * K : 1));
         for (int tyy = 0; tyy < BLOCK_Y; tyy++)
             for (int txx = 0; txx < BLOCK_X; txx++) {
                 uint32_t px = tx * BLOCK_X + txx, py = ty * BLOCK_Y + tyy;
@@ -714,6 +722,8 @@ static void gauss_chain(const HsroChain* c, int idx, const real in[9], real* dme
 typedef struct {
     const HsroState* s;
     const float *colors, *background, *dL_dpix, *dL_dpix_sem, *dL_dpix_depth, *dL_dpix_median, *dL_dpix_opacity;
+    const float* semantics;   /* [P,K] features: read only in sem_alpha_mode 1 */
+    int sem_alpha_mode;       /* 0: reference as observed (the semantic loss never reaches alpha); 1: "exact" (what backward.cu:778-779, :834-845 intended) */
     size_t N; int K, NA;
     real ddelx_dx, ddely_dy;
     int median_rule;
@@ -732,6 +742,10 @@ static int pixel_backward(const HsroBwdCtx* c, size_t pix_id, float pfx, float p
     for (int ch = 0; ch < K; ch++) dsem[ch] = c->dL_dpix_sem[(size_t)ch * N + pix_id];
     real accum_depth_rec = 0, accum_op_rec = 0, last_alpha = 0, last_depth = 0, last_op = 0;
     int pixel_disagrees = 0;
+    /* exact mode: the semantic channels' accum_rec / last value, as the colour channels have (dsem holds 3 K reals then) */
+    real* accum_rec_sem = dsem + K;
+    real* last_sem = dsem + 2 * K;
+    if (c->sem_alpha_mode) for (int ch = 0; ch < 2 * K; ch++) accum_rec_sem[ch] = 0;
 #define ADD(col, v) do { if (local) a[col] += (double)(v); else if (acc32) a32[col] += (float)(v); else { _Pragma("omp atomic") a[col] += (double)(v); } } while (0)
     for (uint32_t ii = r1; ii > r0; ii--) { /* back to front, backward.cu:562, :771 */
         contributor--;
@@ -755,6 +769,14 @@ static int pixel_backward(const HsroBwdCtx* c, size_t pix_id, float pfx, float p
             G = G * (1.0f + u * g_exp_ulps * 1.1920929e-7f);
             alpha = fmin_r(0.99f, co[3] * G);
         }
+        if (acc32 && g_arg_roundings > 0.0f) {   /* fp32 model: the exponent's argument as another evaluation order rounds it (hsro_set_exp_argument_error) */
+            uint64_t hsh = ((uint64_t)pix_id * 0xD6E8FEB86659FD93ull) ^ ((uint64_t)ii * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)g_accum_seed << 32) ^ 0x5851F42D4C957F2Dull;
+            hsh ^= hsh >> 29; hsh *= 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 32;
+            const float u2 = (float)((double)(hsh & 0xFFFFFFu) / 8388607.5 - 1.0);
+            const float S = 0.5f * (fabsf(co[0]) * (float)(dx * dx) + fabsf(co[2]) * (float)(dy * dy)) + fabsf(co[1] * (float)(dx * dy));
+            G = G * (1.0f + u2 * g_arg_roundings * 5.9604645e-8f * S);
+            alpha = fmin_r(0.99f, co[3] * G);
+        }
         real test_T = T / (1.f - alpha);
         const real w = alpha * test_T;
         double* a = local ? local + (size_t)(ii - 1 - r0) * NA : acc + (size_t)id * NA;
@@ -771,6 +793,12 @@ static int pixel_backward(const HsroBwdCtx* c, size_t pix_id, float pfx, float p
         /* semantic: s == 0 (unwritten scratch), accum_rec_sem and last_semantic stay 0, so the
            dL_dalpha term (backward.cu:840) is exactly 0; only dL_dsemantics accumulates (:845) */
         for (int ch = 0; ch < K; ch++) {
+            if (c->sem_alpha_mode) {   /* backward.cu:834-845 with the staging of :778-779 in place: the channel's own (c - accum_rec) term */
+                const real cval = c->semantics[(size_t)id * K + ch];
+                accum_rec_sem[ch] = last_alpha * last_sem[ch] + (1.f - last_alpha) * accum_rec_sem[ch];
+                last_sem[ch] = cval;
+                dL_dalpha += (cval - accum_rec_sem[ch]) * dsem[ch];
+            }
             real v = w * dsem[ch];
             ADD(10 + ch, v);
         }
@@ -859,7 +887,9 @@ static void bounds_add_delta(const HsroChain* ch, HsroBounds* b, uint32_t id, co
  * and are fully overwritten (the reference zero-fills them first, rasterize_points.cu:378-388); they are `real`.
  * dL_dconic is [P,4] (only [0],[1],[3] written, backward.cu:658-660).  dL_dmean2D is [P,3].
  * sem_alpha_mode 0 = reference-as-observed: the semantic->alpha term reads a scratch buffer the
- * reference never writes (backward.cu:834, rasterizer_impl.cu:673-674), i.e. zeros.
+ * reference never writes (backward.cu:834, rasterizer_impl.cu:673-674), i.e. zeros.  1 = "exact": the term as the
+ * commented-out staging (backward.cu:778-779) would have made it — each semantic channel contributes (c - accum_rec) * dL_dchannel
+ * to dL_dalpha like a colour channel; pinned by tests/dense_ref.py(sem_alpha_exact=True) (tests/test_oracle.py).
  * bounds (may be NULL): the tie bounds of the gradients, arrays zero-filled by the caller.
  */
 int hsro_backward(const HsroState* s, int D, int M, const float* background, const float* means3D, const float* shs,
@@ -871,7 +901,8 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
                   real* dL_ddepth, real* dL_dmean3D, real* dL_dcov3D, real* dL_dsh, real* dL_dscale, real* dL_drot,
                   int sem_alpha_mode, HsroBounds* bounds)
 {
-    if (sem_alpha_mode != 0) return -1;
+    if (sem_alpha_mode != 0 && sem_alpha_mode != 1) return -1;
+    if (sem_alpha_mode == 1 && s->semantic && s->K > 0 && !semantics) return -1;
     const int P = s->P, W = s->W, H = s->H, K = s->semantic ? s->K : 0;
     const size_t N = (size_t)W * H;
     const uint32_t gx = (uint32_t)s->tiles_x, gy = (uint32_t)s->tiles_y;
@@ -886,6 +917,7 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
     bc.s = s; bc.colors = colors; bc.background = background; bc.dL_dpix = dL_dpix; bc.dL_dpix_sem = dL_dpix_sem;
     bc.dL_dpix_depth = dL_dpix_depth; bc.dL_dpix_median = dL_dpix_median; bc.dL_dpix_opacity = dL_dpix_opacity;
     bc.N = N; bc.K = K; bc.NA = NA;
+    bc.semantics = semantics; bc.sem_alpha_mode = (K > 0) ? sem_alpha_mode : 0;
     bc.ddelx_dx = (float)(0.5 * W); bc.ddely_dy = (float)(0.5 * H); /* backward.cu:550-551, :759-760 */
     bc.median_rule = g_median_rule;
     long median_disagree = 0;
@@ -910,7 +942,7 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
         const long tile = order[ti];
         const uint32_t ty = (uint32_t)(tile / gx), tx = (uint32_t)(tile % gx);
         const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
-        real* dsem = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
+        real* dsem = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? 3 * K : 1));
         /* fp32 model: the pixels of a tile in a seeded random order too — the reference's 256 threads of a block add with atomicAdd in
          * whatever order the hardware serialises them (backward.cu:616-663), not in raster order, which would add neighbouring (similar)
          * terms one after the other and understate the spread */
@@ -980,8 +1012,8 @@ int hsro_backward(const HsroState* s, int D, int M, const float* background, con
             const size_t tile = (size_t)(py / BLOCK_Y) * gx + px / BLOCK_X;
             const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
             const size_t nl = (size_t)(r1 - r0);
-            real* Sacc = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
-            real* dsem = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? K : 1));
+            real* Sacc = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? 3 * K : 1));
+            real* dsem = (real*)malloc(sizeof(real) * (size_t)(K > 0 ? 3 * K : 1));
             double* base = (double*)calloc((nl ? nl : 1) * (size_t)NA, sizeof(double));
             double* alt = (double*)malloc((nl ? nl : 1) * (size_t)NA * sizeof(double));
             HsroPixFwd f;

@@ -170,12 +170,14 @@ def forward(cam, means3D, opacities, colors_precomp=None, shs=None, semantics_pr
 
 
 def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_precomp=None, scales=None,
-             rotations=None, cov3D_precomp=None, threads=0, median_rule="reference", bounds=False, fp32_atomics_seed=None, exp_ulps=0.0):
+             rotations=None, cov3D_precomp=None, threads=0, median_rule="reference", bounds=False, fp32_atomics_seed=None, exp_ulps=0.0,
+             sem_alpha_exact=False, arg_roundings=0.0):
     """Oracle backward.  grads: dict(color[3,H,W], semantic[K,H,W]|None, depth, median, opacity).
     median_rule: "reference" = the splat the backward re-finds from its reconstructed T (backward.cu:623-626, :854-857);
     "forward" = the splat whose list position the forward recorded (what the HIP product does; identical except where the
     reconstructed T passes within rounding of 0.5).  The result carries `median_rule_disagreements`: the number of pixels on
     which the two rules pick differently.
+    sem_alpha_exact: the semantic loss also reaches alpha (oracle sem_alpha_mode 1; the product's opt-in mode, default off = reference as observed).
     bounds=True: also the tie bounds of the gradients (oracle/hsr_oracle.c, "Threshold ties") as o["bounds"][name] — how far
     each gradient entry moves when the flagged threshold decisions of the flagged pixels are taken the other way."""
     L = lib(st.precision)
@@ -186,6 +188,8 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
     # a GPU's exp (v_exp_f32: 1 ulp; CUDA's expf: 2 ulp documented) instead of glibc's
     L.hsro_set_accumulation(C.c_int(0 if fp32_atomics_seed is None else 1), C.c_uint(int(fp32_atomics_seed or 0)))
     L.hsro_set_exp_error(C.c_float(float(exp_ulps) if fp32_atomics_seed is not None else 0.0))
+    # arg_roundings (fp32 model only): ... and the exponent's argument rounded as another correct fp32 evaluation order would (hsro_set_exp_argument_error)
+    L.hsro_set_exp_argument_error(C.c_float(float(arg_roundings) if fp32_atomics_seed is not None else 0.0))
     L.hsro_set_median_rule(C.c_int({"reference": 0, "forward": 1}[median_rule]))
     if threads:
         L.hsro_set_threads(C.c_int(threads))
@@ -225,7 +229,7 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
                          po("means2D"), po("conic"), po("opacities"), po("colors_precomp"), po("semantics_precomp"),
                          po("depths"), po("means3D"), po("cov3D_precomp"), po("shs"),
                          po("scales") if has_scales else C.c_void_p(0), po("rotations") if has_scales else C.c_void_p(0),
-                         C.c_int(0), C.byref(bstruct) if bstruct is not None else C.c_void_p(0))
+                         C.c_int(1 if sem_alpha_exact else 0), C.byref(bstruct) if bstruct is not None else C.c_void_p(0))
     if rc != 0:
         raise RuntimeError("hsro_backward rc=%d" % rc)
     if bounds:
@@ -236,6 +240,7 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
     L.hsro_set_median_rule(C.c_int(0))
     L.hsro_set_accumulation(C.c_int(0), C.c_uint(0))
     L.hsro_set_exp_error(C.c_float(0.0))
+    L.hsro_set_exp_argument_error(C.c_float(0.0))
     return o
 
 

@@ -85,7 +85,8 @@ def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
     def conditioned(name, got, allowance):
         """Third tier, gradients only: HIP and the fp32 oracle are two fp32 evaluations; where they differ by more than the bound the
         TRUTH build (same lists, arithmetic in double) says who is right.  The noise floor of a gradient = how far the fp32 oracle and
-        eight runs of the fp32-atomics model of the reference's own accumulation (seeded arrival orders), and the fp32 oracle with one upstream gradient at a
+        eight runs of the fp32 model of another correct implementation (the reference's own fp32-atomics accumulation in seeded arrival orders, a 1-ulp
+        exp, the exponent's argument rounded as another evaluation order would: harness.FP32_MODEL_*), and the fp32 oracle with one upstream gradient at a
         time (harness.fp32_error_samples), sit from the truth; HIP passes if
         it is within twice that floor (+ rounding), tensor-wide and element-wise — a defect shows as HIP alone being far.  (Eight orders, not
         four: the largest of a handful of draws from a heavy-tailed spread is a shaky floor — case 2571 of the 3 000-case run with seed
@@ -103,7 +104,8 @@ def _compare(cam, sc, up, semantic, variant, extra=None, grad_rtol=1e-4):
             if not semantic:
                 g_["semantic"] = None
             truth["t"] = gr_t
-            truth["m"] = [O.backward(st_o, cam, sc["means3D"], g_, median_rule="forward", fp32_atomics_seed=seed, exp_ulps=harness.FP32_MODEL_EXP_ULPS, **kw_) for seed in range(8)]
+            truth["m"] = [O.backward(st_o, cam, sc["means3D"], g_, median_rule="forward", fp32_atomics_seed=seed, exp_ulps=harness.FP32_MODEL_EXP_ULPS,
+                                     arg_roundings=harness.FP32_MODEL_ARG_ROUNDINGS, **kw_) for seed in range(8)]
         key = name.replace("grad ", "")
         t = np.asarray(truth["t"][key], np.float64).reshape(np.asarray(got).shape)
         mx = max(float(np.abs(t).max()), 1e-30)

@@ -26,6 +26,27 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
 
 
+@pytest.mark.parametrize("kind,bg", [("aniso", (0.3, 0.6, 0.1)), ("slam", (0, 0, 0))])
+def test_oracle_exact_semantic_alpha_mode_matches_float64_autograd(kind, bg):
+    """sem_alpha_mode 1 ("exact": the semantic loss also reaches alpha, what backward.cu:778-779 / :834-845 intended; the product's opt-in
+    `set_semantic_alpha("exact")`): pinned by the same float64 autograd restatement with the term kept (w not detached in the semantic sums).
+    It must differ from the default mode wherever a semantic gradient flows, and leave dL_dsemantics itself unchanged."""
+    W, H, K, P = 40, 36, 5, 60
+    cam, sc, up = scenes.build(W, H, P, K, seed=3, kind=kind, scale_mult=4.0, bg=bg)
+    out, gr0, st = run_oracle(cam, sc, up, semantic=True, threads=2)
+    g = {n: v.numpy() for n, v in up.items()}
+    kw = dict(colors_precomp=sc["colors_precomp"], semantics_precomp=sc["semantics_precomp"], scales=sc["scales"], rotations=sc["rotations"])
+    gr = O.backward(st, cam, sc["means3D"], g, threads=2, median_rule="forward", sem_alpha_exact=True, **kw)
+    dout, dgr = DR.dense_loss_and_grads(cam, sc, g, st.field("vals"), st.field("ranges"), semantic=True, sem_alpha_exact=True)
+    for a, b in dict(means3D="means3D", scales="scales", rotations="rotations", opacities="opacities_ref", colors_precomp="colors",
+                     semantics_precomp="semantics").items():
+        assert _rel(gr[a], dgr[b].numpy()) < 2e-5, (a, _rel(gr[a], dgr[b].numpy()))
+    assert _rel(gr["means2D"][:, :2], dgr["ndc_delta"].numpy()) < 2e-5
+    assert _rel(gr["semantics_precomp"], gr0["semantics_precomp"]) < 1e-12          # sum w * dL_dsem: the same in both modes
+    assert _rel(gr["opacities"], gr0["opacities"]) > 1e-3 and _rel(gr["means3D"], gr0["means3D"]) > 1e-3   # the term is not small
+    st.free()
+
+
 @pytest.mark.parametrize("kind,semantic,bg", [("aniso", True, (0.3, 0.6, 0.1)), ("slam", True, (0, 0, 0)),
                                               ("aniso", False, (0.0, 0.0, 0.0))])
 def test_oracle_matches_float64_autograd(kind, semantic, bg):
@@ -407,3 +428,37 @@ def test_tie_bound_covers_a_decision_forced_the_other_way():
     # rows of splats that never touch the flagged pixel carry no bound at all
     assert float(sa.grad_bounds["means3D"][~sa.field("tie_gaussians").astype(bool)].max(initial=0.0)) == 0.0
     sa.free(); sb.free()
+
+
+def test_fp32_model_of_the_exponents_argument_rounding():
+    """The noise-floor model of tests/harness.py (FP32_MODEL_ARG_ROUNDINGS; oracle/hsr_oracle.c hsro_set_exp_argument_error): the exponent's
+    argument is a sum of three products that cancel on elongated, rotated splats, so another correct fp32 evaluation order lands G further
+    away than one ulp of exp does — measured here on the oracle alone: the distance of the fp32 model from the truth build with the
+    argument rounding on, against the same seeds with it off.  Off = the model as it was (bit for bit); on = a bounded, larger spread."""
+    import harness
+    W, H, P, K = 120, 72, 800, 4
+    cam, sc, up = scenes.build(W, H, P, K, seed=77, kind="aniso", scale_mult=3.0)
+    # needles: one axis 8x longer still
+    sc["scales"] = sc["scales"].clone()
+    sc["scales"][:, 2] = sc["scales"][:, 2] * 8.0
+    kw = dict(harness.variant_kwargs(sc, "sr", None), semantics_precomp=sc["semantics_precomp"])
+    g_ = {n: v.numpy() for n, v in up.items()}
+    _, gt, st_t = run_oracle(cam, sc, up, semantic=True, precision="f64", bounds=False)
+    st_t.free()
+    _, _, st = run_oracle(cam, sc, up, semantic=True, bounds=False)
+    def model(seed, e, a):
+        return O.backward(st, cam, sc["means3D"], g_, median_rule="forward", fp32_atomics_seed=seed, exp_ulps=e, arg_roundings=a, **kw)
+    def dist(g, n):
+        t = np.asarray(gt[n], np.float64)
+        return float(np.abs(np.asarray(g[n], np.float64).reshape(t.shape) - t).max() / np.abs(t).max())
+    off = [model(s, 1.0, 0.0) for s in range(4)]
+    on = [model(s, 1.0, harness.FP32_MODEL_ARG_ROUNDINGS) for s in range(4)]
+    again = model(0, 1.0, 0.0)
+    for n in ("means3D", "rotations", "scales", "opacities"):
+        assert np.array_equal(off[0][n], again[n]), n          # seeded: the same model run twice is the same bits
+        d_off, d_on = max(dist(g, n) for g in off), max(dist(g, n) for g in on)
+        print("%-10s fp32 model vs truth, tensor-wide: orders + 1-ulp exp %.2e ; + argument rounding %.2e" % (n, d_off, d_on))
+        assert d_on < 20.0 * max(d_off, 1e-5), (n, d_on, d_off)   # bounded: a rounding model, not a different function
+    # dL_dopacity is a plain sum of G dL_dalpha (no ill-conditioned chain behind it): there the argument rounding shows by itself
+    assert max(dist(g, "opacities") for g in on) > 2.0 * max(dist(g, "opacities") for g in off)
+    st.free()
