@@ -216,9 +216,18 @@ __global__ __launch_bounds__(PREP_BLOCK) void frame_prep_backward_kernel(
 
 // One block: sums the per-block partials in a fixed order (double), then the 3x3 -> quaternion adjoint and the two
 // normalisation adjoints (build_rotation's and F.normalize's), and writes the 4 + 3 pose gradients.
+// param_shaped: d_cam_rot / d_cam_tran are shaped like the parameters ([4][num_frames] / [3][num_frames]): every column but time_idx is
+// zeroed here and the gradient lands in column time_idx — what the caller would otherwise do with two fills and two strided copies.
 __global__ __launch_bounds__(PREP_FINISH_BLOCK) void frame_prep_finish_kernel(PrepArgs a, const float* __restrict__ partials, int nblocks,
-                                                                      float* __restrict__ d_cam_rot, float* __restrict__ d_cam_tran)
+                                                                      float* __restrict__ d_cam_rot, float* __restrict__ d_cam_tran,
+                                                                      int param_shaped)
 {
+    const int cs = param_shaped ? a.num_frames : 1;          // stride between the components of the pose gradient
+    const int c0 = param_shaped ? a.time_idx : 0;            // ... and where component 0 sits
+    if (param_shaped) {
+        if (d_cam_rot) for (int i = threadIdx.x; i < 4 * a.num_frames; i += PREP_FINISH_BLOCK) d_cam_rot[i] = 0.f;
+        if (d_cam_tran) for (int i = threadIdx.x; i < 3 * a.num_frames; i += PREP_FINISH_BLOCK) d_cam_tran[i] = 0.f;
+    }
     constexpr int ROWS = PREP_FINISH_BLOCK / PREP_SUMS;
     __shared__ double s_acc[ROWS][PREP_SUMS];
     const int k = threadIdx.x % PREP_SUMS, j = threadIdx.x / PREP_SUMS;
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(PREP_FINISH_BLOCK) void frame_prep_finish_kernel(Pr
     double S[PREP_SUMS];
     for (int c = 0; c < PREP_SUMS; c++) S[c] = s_tot[c];
     const Pose ps = load_pose(a.cam_unnorm_rots, a.cam_trans, a.num_frames, a.time_idx);
-    if (d_cam_tran) { d_cam_tran[0] = (float)S[0]; d_cam_tran[1] = (float)S[1]; d_cam_tran[2] = (float)S[2]; }
+    if (d_cam_tran) { d_cam_tran[c0] = (float)S[0]; d_cam_tran[c0 + cs] = (float)S[1]; d_cam_tran[c0 + 2 * cs] = (float)S[2]; }
     if (!d_cam_rot) return;
     const double r = ps.qq[0], x = ps.qq[1], y = ps.qq[2], z = ps.qq[3];
     const double* M = S + 3;  // M[3*i + j]
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(PREP_FINISH_BLOCK) void frame_prep_finish_kernel(Pr
         const double n = fmax((double)ps.nhat, 1e-12);
         double d = 0.0;
         for (int c = 0; c < 4; c++) d += (double)ps.q[c] * dq[c];
-        for (int c = 0; c < 4; c++) d_cam_rot[c] = (float)((dq[c] - (double)ps.q[c] * d) / n);
+        for (int c = 0; c < 4; c++) d_cam_rot[c0 + c * cs] = (float)((dq[c] - (double)ps.q[c] * d) / n);
     }
 }
 
@@ -321,14 +330,15 @@ extern "C" int hsr_frame_prep_forward(int P, int S, int transform_rots, int rot_
     return HSR_OK;
 }
 
-extern "C" int hsr_frame_prep_backward(int P, int S, int transform_rots, int rot_source, const float* means3D,
-                                       const float* unnorm_rotations, const float* logit_opacities, const float* log_scales,
-                                       const float* cam_unnorm_rots, const float* cam_trans, int num_frames, int time_idx,
-                                       const float* w2c, const float* dL_dout_means3D, const float* dL_dout_unnorm_rot,
-                                       const float* dL_dout_rotations, const float* dL_dout_opacities, const float* dL_dout_scales,
-                                       const float* dL_dout_depth_sil, float* dL_dmeans3D, float* dL_dunnorm_rotations,
-                                       float* dL_dlogit_opacities, float* dL_dlog_scales, float* dL_dcam_unnorm_rot,
-                                       float* dL_dcam_tran, char* scratch, size_t scratch_bytes, void* stream_)
+namespace {
+int frame_prep_backward_impl(int P, int S, int transform_rots, int rot_source, const float* means3D,
+                             const float* unnorm_rotations, const float* logit_opacities, const float* log_scales,
+                             const float* cam_unnorm_rots, const float* cam_trans, int num_frames, int time_idx,
+                             const float* w2c, const float* dL_dout_means3D, const float* dL_dout_unnorm_rot,
+                             const float* dL_dout_rotations, const float* dL_dout_opacities, const float* dL_dout_scales,
+                             const float* dL_dout_depth_sil, float* dL_dmeans3D, float* dL_dunnorm_rotations,
+                             float* dL_dlogit_opacities, float* dL_dlog_scales, float* dL_dcam_unnorm_rot,
+                             float* dL_dcam_tran, char* scratch, size_t scratch_bytes, void* stream_, int param_shaped)
 {
     hipStream_t stream = (hipStream_t)stream_;
     int rc = check_common(P, S, rot_source, means3D, unnorm_rotations, logit_opacities, log_scales, cam_unnorm_rots, cam_trans,
@@ -355,8 +365,39 @@ extern "C" int hsr_frame_prep_backward(int P, int S, int transform_rots, int rot
         HSR_HIP_CHECK(hipGetLastError());
     }
     if (dL_dcam_unnorm_rot || dL_dcam_tran) {
-        frame_prep_finish_kernel<<<1, PREP_FINISH_BLOCK, 0, stream>>>(a, partials, nblocks, dL_dcam_unnorm_rot, dL_dcam_tran);
+        frame_prep_finish_kernel<<<1, PREP_FINISH_BLOCK, 0, stream>>>(a, partials, nblocks, dL_dcam_unnorm_rot, dL_dcam_tran, param_shaped);
         HSR_HIP_CHECK(hipGetLastError());
     }
     return HSR_OK;
+}
+}  // namespace
+
+extern "C" int hsr_frame_prep_backward(int P, int S, int transform_rots, int rot_source, const float* means3D,
+                                       const float* unnorm_rotations, const float* logit_opacities, const float* log_scales,
+                                       const float* cam_unnorm_rots, const float* cam_trans, int num_frames, int time_idx,
+                                       const float* w2c, const float* dL_dout_means3D, const float* dL_dout_unnorm_rot,
+                                       const float* dL_dout_rotations, const float* dL_dout_opacities, const float* dL_dout_scales,
+                                       const float* dL_dout_depth_sil, float* dL_dmeans3D, float* dL_dunnorm_rotations,
+                                       float* dL_dlogit_opacities, float* dL_dlog_scales, float* dL_dcam_unnorm_rot,
+                                       float* dL_dcam_tran, char* scratch, size_t scratch_bytes, void* stream_)
+{
+    return frame_prep_backward_impl(P, S, transform_rots, rot_source, means3D, unnorm_rotations, logit_opacities, log_scales, cam_unnorm_rots,
+                                    cam_trans, num_frames, time_idx, w2c, dL_dout_means3D, dL_dout_unnorm_rot, dL_dout_rotations,
+                                    dL_dout_opacities, dL_dout_scales, dL_dout_depth_sil, dL_dmeans3D, dL_dunnorm_rotations,
+                                    dL_dlogit_opacities, dL_dlog_scales, dL_dcam_unnorm_rot, dL_dcam_tran, scratch, scratch_bytes, stream_, 0);
+}
+
+extern "C" int hsr_frame_prep_backward_params(int P, int S, int transform_rots, int rot_source, const float* means3D,
+                                              const float* unnorm_rotations, const float* logit_opacities, const float* log_scales,
+                                              const float* cam_unnorm_rots, const float* cam_trans, int num_frames, int time_idx,
+                                              const float* w2c, const float* dL_dout_means3D, const float* dL_dout_unnorm_rot,
+                                              const float* dL_dout_rotations, const float* dL_dout_opacities, const float* dL_dout_scales,
+                                              const float* dL_dout_depth_sil, float* dL_dmeans3D, float* dL_dunnorm_rotations,
+                                              float* dL_dlogit_opacities, float* dL_dlog_scales, float* dL_dcam_unnorm_rots,
+                                              float* dL_dcam_trans, char* scratch, size_t scratch_bytes, void* stream_)
+{
+    return frame_prep_backward_impl(P, S, transform_rots, rot_source, means3D, unnorm_rotations, logit_opacities, log_scales, cam_unnorm_rots,
+                                    cam_trans, num_frames, time_idx, w2c, dL_dout_means3D, dL_dout_unnorm_rot, dL_dout_rotations,
+                                    dL_dout_opacities, dL_dout_scales, dL_dout_depth_sil, dL_dmeans3D, dL_dunnorm_rotations,
+                                    dL_dlogit_opacities, dL_dlog_scales, dL_dcam_unnorm_rots, dL_dcam_trans, scratch, scratch_bytes, stream_, 1);
 }

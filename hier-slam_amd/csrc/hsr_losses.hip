@@ -327,6 +327,146 @@ __global__ __launch_bounds__(LB) void tree_ce_kernel(const float* __restrict__ l
         for (int c = covered_end; c < K; c++) grad[(size_t)c * N + p] = 0.f;   // channels behind the last level
 }
 
+// Two-pass form (round 4): the value pass counts the valid labels itself and writes no gradient; the gradient pass runs when autograd
+// asks for it and multiplies by the upstream gradient it reads from device memory — no label pre-pass, no stashed K x H x W gradient, no
+// `stash * g` multiply afterwards (at 1200 x 680, K = 26: 76 + 35 + 23 us of launches became 2 passes of 118 and 203 MB).
+// A level of at most CE_REG channels is held in registers: all its loads go out together, one expf per channel, no second read.
+constexpr int CE_REG = 16;
+
+template <bool GRAD>
+__global__ __launch_bounds__(LB) void tree_ce2_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int N, int K,
+                                                      Levels lv, int ignore_index, const float* __restrict__ inv_count,
+                                                      const float* __restrict__ upstream, float* __restrict__ grad,
+                                                      float* __restrict__ partials /* [nblk][2 * MAX_LEVELS]: loss sums, then counts */)
+{
+    __shared__ float s_part[4][2 * HSR_LOSS_MAX_LEVELS];
+    const int i = blockIdx.x * LB + threadIdx.x;
+    const bool live = i < N;
+    const size_t p = live ? (size_t)i : 0;
+    const float up = GRAD ? (upstream ? upstream[0] : 1.0f) : 0.f;
+    float lsum[HSR_LOSS_MAX_LEVELS], lcnt[HSR_LOSS_MAX_LEVELS];
+    int covered_end = 0;
+#pragma unroll 1
+    for (int l = 0; l < lv.n; l++) {
+        const int b = lv.begin[l], n = lv.size[l];
+        const int64_t lab64 = labels[(size_t)l * N + p];
+        const bool valid = live && lab64 != (int64_t)ignore_index;
+        const int lab = (int)lab64;
+        const float sc = GRAD ? (valid ? lv.weight[l] * inv_count[l] * up : 0.f) : 0.f;
+        float loss = 0.f;
+        if (n <= CE_REG) {
+            float z[CE_REG];
+#pragma unroll
+            for (int c = 0; c < CE_REG; c++) z[c] = c < n ? logits[(size_t)(b + min(c, n - 1)) * N + p] : -INFINITY;
+            float m = z[0];
+#pragma unroll
+            for (int c = 1; c < CE_REG; c++) m = fmaxf(m, z[c]);
+            float s = 0.f, picked = 0.f;
+#pragma unroll
+            for (int c = 0; c < CE_REG; c++) {
+                picked = c == lab ? z[c] : picked;
+                z[c] = c < n ? expf(z[c] - m) : 0.f;
+                s += z[c];
+            }
+            if (GRAD) {
+                const float inv_s = 1.0f / s;
+                if (live) {
+#pragma unroll
+                    for (int c = 0; c < CE_REG; c++)
+                        if (c < n) grad[(size_t)(b + c) * N + p] = (z[c] * inv_s - (c == lab ? 1.f : 0.f)) * sc;
+                }
+            } else {
+                loss = valid ? (m + logf(s)) - picked : 0.f;
+            }
+        } else {
+            // wide level: stream it (online log-sum-exp, second read from L2)
+            float m = -INFINITY, s = 0.f, picked = 0.f;
+            for (int c = 0; c < n; c++) {
+                const float z = logits[(size_t)(b + c) * N + p];
+                const float nm = fmaxf(m, z);
+                s = s * expf(m - nm) + expf(z - nm);
+                m = nm;
+                picked = c == lab ? z : picked;
+            }
+            if (GRAD) {
+                const float inv_s = 1.0f / s;
+                if (live)
+                    for (int c = 0; c < n; c++) {
+                        const float z = logits[(size_t)(b + c) * N + p];
+                        grad[(size_t)(b + c) * N + p] = (expf(z - m) * inv_s - (c == lab ? 1.f : 0.f)) * sc;
+                    }
+            } else {
+                loss = valid ? (m + logf(s)) - picked : 0.f;
+            }
+        }
+        lsum[l] = loss;
+        lcnt[l] = valid ? 1.f : 0.f;
+        covered_end = b + n;
+    }
+    if (GRAD) {
+        if (live)
+            for (int c = covered_end; c < K; c++) grad[(size_t)c * N + p] = 0.f;   // channels behind the last level
+        return;
+    }
+    // one reduction for all levels: wave sums, then the four waves in a fixed order (counts are exact in fp32: <= 256 per block)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int l = 0; l < lv.n; l++) {
+        float a = lsum[l], c = lcnt[l];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            c += __shfl_xor(c, o, 64);
+        }
+        if (lane == 0) {
+            s_part[wv][l] = a;
+            s_part[wv][HSR_LOSS_MAX_LEVELS + l] = c;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * HSR_LOSS_MAX_LEVELS) {
+        const int k = threadIdx.x;
+        partials[(size_t)blockIdx.x * (2 * HSR_LOSS_MAX_LEVELS) + k] =
+            (k % HSR_LOSS_MAX_LEVELS) < lv.n ? ((s_part[0][k] + s_part[1][k]) + s_part[2][k]) + s_part[3][k] : 0.f;
+    }
+}
+
+// one block of 1024: level l -> loss sum / count and 1 / count, fixed order, in double.  Thread t sums column t % 32 of rows t / 32,
+// t / 32 + 32, ... with four independent loads in flight (a serial walk of 3 188 rows by 8 row groups took 94 us: latency, not bytes).
+constexpr int CEF_T = 1024;
+__global__ __launch_bounds__(CEF_T) void tree_ce_finish_kernel(const float* __restrict__ partials, int nblocks, int num_levels,
+                                                               float* __restrict__ out_level_loss, float* __restrict__ out_inv_count)
+{
+    constexpr int COLS = 2 * HSR_LOSS_MAX_LEVELS, ROWS = CEF_T / COLS;
+    __shared__ double s_acc[ROWS][COLS + 1];
+    __shared__ double s_tot[COLS];
+    const int k = threadIdx.x % COLS, j = threadIdx.x / COLS;
+    double acc = 0.0;
+    if ((k % HSR_LOSS_MAX_LEVELS) < num_levels) {
+        int b = j;
+        for (; b + 3 * ROWS < nblocks; b += 4 * ROWS) {
+            const float v0 = partials[(size_t)b * COLS + k], v1 = partials[(size_t)(b + ROWS) * COLS + k];
+            const float v2 = partials[(size_t)(b + 2 * ROWS) * COLS + k], v3 = partials[(size_t)(b + 3 * ROWS) * COLS + k];
+            acc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < nblocks; b += ROWS) acc += (double)partials[(size_t)b * COLS + k];
+    }
+    s_acc[j][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < COLS) {
+        double v = 0.0;
+        for (int r = 0; r < ROWS; r++) v += s_acc[r][threadIdx.x];
+        s_tot[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < num_levels) {
+        // 0 valid labels: 1 / 0 = +inf and 0 * inf = NaN, torch's mean over an empty selection; the gradient pass writes 0 there
+        const float inv = 1.0f / (float)s_tot[HSR_LOSS_MAX_LEVELS + threadIdx.x];
+        out_inv_count[threadIdx.x] = inv;
+        out_level_loss[threadIdx.x] = (float)(s_tot[threadIdx.x] * (double)inv);
+    }
+}
+
 // ---------------------------------------------------------------- leaf head: 1x1-conv MLP + cross-entropy, fused
 // logits[c] = b[c] + sum_k Wt[c][k] * sem[k]  per pixel (torch.nn.Conv2d(K, C, 1), scripts/hierslam.py:1756), CrossEntropyLoss on
 // them (scripts/hierslam.py:976-983), and the three gradients.  One thread per pixel (lane = pixel):
@@ -686,6 +826,85 @@ extern "C" int hsr_loss_tree_ce(int K, int H, int W, int num_levels, const int* 
     count_finish_kernel<<<1, LB, 0, stream>>>(cparts, nb, HSR_LOSS_MAX_LEVELS, num_levels, inv);
     tree_ce_kernel<<<nb, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, inv, out_grad, partials);
     finish_kernel<<<1, LB, 0, stream>>>(partials, nb, HSR_LOSS_MAX_LEVELS, num_levels, inv, 1.0f, out_level_loss);
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+namespace {
+int parse_levels(const char* who, int K, int H, int W, int num_levels, const int* level_sizes, const float* level_weight, Levels* lv)
+{
+    if (K < 1 || H < 1 || W < 1 || (size_t)H * W > 0x7fffffffu || !level_sizes) {
+        hsr_set_error("%s: invalid sizes K=%d H=%d W=%d or NULL level_sizes", who, K, H, W);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (num_levels < 1 || num_levels > HSR_LOSS_MAX_LEVELS) {
+        hsr_set_error("%s: num_levels=%d outside [1, %d]", who, num_levels, HSR_LOSS_MAX_LEVELS);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    lv->n = num_levels;
+    int begin = 0;
+    for (int l = 0; l < num_levels; l++) {
+        if (level_sizes[l] < 1) {
+            hsr_set_error("%s: level %d has %d classes", who, l, level_sizes[l]);
+            return HSR_ERR_INVALID_ARGUMENT;
+        }
+        lv->begin[l] = begin;
+        lv->size[l] = level_sizes[l];
+        lv->weight[l] = level_weight ? level_weight[l] : 1.0f;
+        begin += level_sizes[l];
+    }
+    if (begin > K) {
+        hsr_set_error("%s: levels cover %d channels but the map has K=%d", who, begin, K);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    return HSR_OK;
+}
+}  // namespace
+
+extern "C" size_t hsr_loss_tree_ce_scratch_bytes(int H, int W)
+{
+    if (H < 1 || W < 1) return 1024;
+    const size_t nb = ((size_t)H * W + LB - 1) / LB;
+    return align256(nb * 2 * HSR_LOSS_MAX_LEVELS * sizeof(float)) + 256;
+}
+
+extern "C" int hsr_loss_tree_ce_value(int K, int H, int W, int num_levels, const int* level_sizes, const float* logits,
+                                      const int64_t* labels, int ignore_index, float* out_level_loss, float* out_inv_count,
+                                      char* scratch, size_t scratch_bytes, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    Levels lv;
+    int rc = parse_levels("loss_tree_ce_value", K, H, W, num_levels, level_sizes, nullptr, &lv);
+    if (rc != HSR_OK) return rc;
+    if (!logits || !labels || !out_level_loss || !out_inv_count) {
+        hsr_set_error("loss_tree_ce_value: NULL logits / labels / out_level_loss / out_inv_count");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    const int N = H * W;
+    const int nb = (N + LB - 1) / LB;
+    rc = check_scratch("loss_tree_ce_value", scratch, scratch_bytes, hsr_loss_tree_ce_scratch_bytes(H, W) - 256);
+    if (rc != HSR_OK) return rc;
+    float* partials = reinterpret_cast<float*>(scratch);
+    tree_ce2_kernel<false><<<nb, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, nullptr, nullptr, nullptr, partials);
+    tree_ce_finish_kernel<<<1, CEF_T, 0, stream>>>(partials, nb, num_levels, out_level_loss, out_inv_count);
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+extern "C" int hsr_loss_tree_ce_grad(int K, int H, int W, int num_levels, const int* level_sizes, const float* level_weight,
+                                     const float* logits, const int64_t* labels, int ignore_index, const float* inv_count,
+                                     const float* upstream, float* out_grad, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    Levels lv;
+    int rc = parse_levels("loss_tree_ce_grad", K, H, W, num_levels, level_sizes, level_weight, &lv);
+    if (rc != HSR_OK) return rc;
+    if (!logits || !labels || !inv_count || !out_grad) {
+        hsr_set_error("loss_tree_ce_grad: NULL logits / labels / inv_count / out_grad");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    const int N = H * W;
+    tree_ce2_kernel<true><<<(N + LB - 1) / LB, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, inv_count, upstream, out_grad, nullptr);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
 }

@@ -78,6 +78,17 @@ def _call(fn, args, debug, dump_name, when, **options):
         raise
 
 
+_zero_maps = {}   # (device, shape) -> a float32 zero tensor that is only ever READ (see _Rasterize.backward)
+
+
+def _zeros_for(shape, device):
+    key = (device, tuple(shape))
+    z = _zero_maps.get(key)
+    if z is None:
+        z = _zero_maps[key] = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+    return z
+
+
 class _Rasterize(torch.autograd.Function):
     """One autograd node for both variants.  Inputs (semantic variant):
     means3D, means2D, sh, colors_precomp, semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, settings;
@@ -104,6 +115,11 @@ class _Rasterize(torch.autograd.Function):
         ctx.semantic = semantic
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        # Outputs the loss does not use arrive in backward() as None instead of freshly zero-filled maps (autograd's default fills
+        # one per unused output per step: a tracking iteration that looks at depth and colour only would fill — and the tile kernel
+        # read — a K x H x W map of zeros every time).  backward() hands the library a cached, never-written zero map in their place.
+        ctx.set_materialize_grads(False)
+        ctx.map_shapes = (tuple(color.shape), tuple(aux.shape), tuple(depth.shape), tuple(median_depth.shape), tuple(final_opacity.shape))
         ctx.save_for_backward(colors_precomp, semantics_precomp if semantic else torch.empty(0), means3D, scales, rotations,
                               cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
@@ -121,6 +137,18 @@ class _Rasterize(torch.autograd.Function):
         else:
             grad_depth, grad_median, grad_opacity = g2, g3, g4  # g5 = grad of mask: ignored, like the reference (:101)
             grad_sem = None
+        dev = means3D.device
+        sh_color, sh_aux, sh_depth, sh_median, sh_opacity = ctx.map_shapes
+        if grad_color is None:
+            grad_color = _zeros_for(sh_color, dev)
+        if grad_depth is None:
+            grad_depth = _zeros_for(sh_depth, dev)
+        if grad_median is None:
+            grad_median = _zeros_for(sh_median, dev)
+        if grad_opacity is None:
+            grad_opacity = _zeros_for(sh_opacity, dev)
+        if ctx.semantic and grad_sem is None:
+            grad_sem = _zeros_for(sh_aux, dev)
         tail = (sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning, img, rs.debug)
         head = (rs.bg, means3D, radii, colors_precomp)
         mid = (scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,

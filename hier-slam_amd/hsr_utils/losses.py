@@ -29,6 +29,12 @@ _lib.hsr_loss_ssim.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
 _lib.hsr_loss_tree_ce.restype = _ci
 _lib.hsr_loss_tree_ce.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), C.POINTER(C.c_float), _vp, _vp, _ci, _vp, _vp, _vp, _sz, _vp]
 
+_lib.hsr_loss_tree_ce_scratch_bytes.restype = _sz
+_lib.hsr_loss_tree_ce_scratch_bytes.argtypes = [_ci, _ci]
+_lib.hsr_loss_tree_ce_value.restype = _ci
+_lib.hsr_loss_tree_ce_value.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), _vp, _vp, _ci, _vp, _vp, _vp, _sz, _vp]
+_lib.hsr_loss_tree_ce_grad.restype = _ci
+_lib.hsr_loss_tree_ce_grad.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), C.POINTER(C.c_float), _vp, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.hsr_loss_leaf_mlp_ce.restype = _ci
 _lib.hsr_loss_leaf_mlp_ce.argtypes = [_ci, _ci, _ci, _ci] + [_vp] * 4 + [_ci] + [_vp] * 5 + [_sz, _vp]
 
@@ -126,15 +132,20 @@ class _TreeCE(torch.autograd.Function):
         lab = lab[:L].to(device=dev, dtype=torch.int64).contiguous()   # the reference calls .long()
         sizes = (_ci * L)(*[int(s) for s in level_sizes])
         w = None if weights is None else (C.c_float * L)(*[float(x) for x in weights])
+        # value now, gradient when (and if) autograd asks for it — the gradient pass multiplies by the incoming gradient itself, so
+        # no K x H x W gradient is stashed and none is multiplied by `g` afterwards (include/hsr_losses.h, hsr_loss_tree_ce_value / _grad)
         out = torch.empty(L, dtype=torch.float32, device=dev)
-        grad = torch.empty_like(z) if logits.requires_grad else None
-        sc = _scratch(K, H, W, dev)
+        inv = torch.empty(L, dtype=torch.float32, device=dev)
+        sc = torch.empty(int(_lib.hsr_loss_tree_ce_scratch_bytes(H, W)), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            rc = _lib.hsr_loss_tree_ce(K, H, W, L, sizes, w, z.data_ptr(), lab.data_ptr(), int(ignore_index), out.data_ptr(),
-                                       None if grad is None else grad.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev))
+            rc = _lib.hsr_loss_tree_ce_value(K, H, W, L, sizes, z.data_ptr(), lab.data_ptr(), int(ignore_index), out.data_ptr(),
+                                             inv.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev))
         if rc < 0:
-            _glue._fail(rc, "hsr_loss_tree_ce")
-        ctx.grad = None if grad is None else grad.view(logits.shape)
+            _glue._fail(rc, "hsr_loss_tree_ce_value")
+        ctx.want = bool(logits.requires_grad)
+        if ctx.want:
+            ctx.save_for_backward(z, lab, inv)
+            ctx.meta = (K, H, W, L, sizes, w, int(ignore_index), tuple(logits.shape))
         ctx.mark_non_differentiable(out)
         if weights is None:
             return out.sum(), out
@@ -145,8 +156,56 @@ class _TreeCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, g_levels):
-        # the stashed gradient is that of the weighted sum; per-level outputs are reported values (no gradient path)
-        return (None if ctx.grad is None or g_total is None else ctx.grad * g_total), None, None, None, None
+        # the gradient of the weighted sum; per-level outputs are reported values (no gradient path)
+        if not ctx.want or g_total is None:
+            return None, None, None, None, None
+        z, lab, inv = ctx.saved_tensors
+        K, H, W, L, sizes, w, ignore_index, shape = ctx.meta
+        dev = z.device
+        g = g_total.to(device=dev, dtype=torch.float32).contiguous()
+        grad = torch.empty_like(z)
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_tree_ce_grad(K, H, W, L, sizes, w, z.data_ptr(), lab.data_ptr(), ignore_index, inv.data_ptr(), g.data_ptr(),
+                                            grad.data_ptr(), _stream(dev))
+        if rc < 0:
+            _glue._fail(rc, "hsr_loss_tree_ce_grad")
+        return grad.view(shape), None, None, None, None
+
+
+class _WeightedSum(torch.autograd.Function):
+    """constant + sum_i w_i * term_i over 0-dim device tensors with Python-float weights, as ONE autograd node.  The reference composes its
+    loss with Python arithmetic on 0-dim tensors (scripts/hierslam.py:1003-1016: `0.8 * l1 + 0.2 * (1.0 - ssim)`, the weighted dictionary
+    sum): every `*`, `+`, `1.0 -` there is a kernel launch forward and another backward — sixteen ~4 us launches around a mapping iteration's
+    three loss heads.  Here: stack + dot forward, one scale backward (the terms' gradients are views of it)."""
+
+    @staticmethod
+    def forward(ctx, wvec, *terms):
+        ctx.save_for_backward(wvec)
+        return torch.dot(torch.stack(terms), wvec)
+
+    @staticmethod
+    def backward(ctx, g):
+        (wvec,) = ctx.saved_tensors
+        return (None,) + tuple((wvec * g).unbind(0))
+
+
+def weighted_sum(terms, weights, constant=0.0):
+    """constant + sum_i weights[i] * terms[i]; terms: 0-dim float32 tensors on one device (loss heads), weights / constant: Python floats."""
+    terms = list(terms)
+    if len(terms) != len(weights) or not terms:
+        raise RuntimeError("hsr_utils.losses.weighted_sum: %d terms for %d weights" % (len(terms), len(weights)))
+    dev = terms[0].device
+    w = [float(x) for x in weights]
+    if constant:
+        key1 = ("one", dev)
+        if key1 not in _weight_cache:
+            _weight_cache[key1] = torch.ones((), dtype=torch.float32, device=dev)
+        terms.append(_weight_cache[key1])
+        w.append(float(constant))
+    key = (tuple(w), dev)
+    if key not in _weight_cache:
+        _weight_cache[key] = torch.tensor(w, dtype=torch.float32, device=dev)
+    return _WeightedSum.apply(_weight_cache[key], *terms)
 
 
 def l1_loss_v1(x, y):
@@ -169,7 +228,7 @@ def calc_ssim(img1, img2, window_size=11, size_average=True):
 
 def mapping_image_loss(im, gt):
     """0.8 * l1_loss_v1(im, gt) + 0.2 * (1.0 - calc_ssim(im, gt))   (scripts/hierslam.py:939)"""
-    return 0.8 * l1_loss_v1(im, gt) + 0.2 * (1.0 - calc_ssim(im, gt))
+    return weighted_sum((l1_loss_v1(im, gt), calc_ssim(im, gt)), (0.8, -0.2), constant=0.2)
 
 
 def tree_cross_entropy(im_semantic, labels, num_semantic, weights=None, ignore_index=-100, return_levels=False):

@@ -34,6 +34,8 @@ _lib.hsr_frame_prep_forward.restype = _ci
 _lib.hsr_frame_prep_forward.argtypes = [_ci, _ci, _ci, _ci] + [_vp] * 6 + [_ci, _ci] + [_vp] * 8
 _lib.hsr_frame_prep_backward.restype = _ci
 _lib.hsr_frame_prep_backward.argtypes = [_ci, _ci, _ci, _ci] + [_vp] * 6 + [_ci, _ci] + [_vp] * 14 + [_sz, _vp]
+_lib.hsr_frame_prep_backward_params.restype = _ci
+_lib.hsr_frame_prep_backward_params.argtypes = _lib.hsr_frame_prep_backward.argtypes
 
 
 def _dev_f32(t, what):
@@ -123,22 +125,23 @@ class _FramePrep(torch.autograd.Function):
         d_unnorm = alloc("unnorm_rotations", (P, 4))
         d_logit = alloc("logit_opacities", tuple(logit_opacities.shape))
         d_ls = alloc("log_scales", tuple(log_scales.shape))
-        d_cam = torch.empty(7, **o)
+        # pose gradients shaped like the parameters: the finish kernel zeroes the other frames' columns itself
+        d_rots = torch.empty_like(cam_unnorm_rots) if camera_grad else None
+        d_trans = torch.empty_like(cam_trans) if camera_grad else None
         scratch = torch.empty(int(_lib.hsr_frame_prep_scratch_bytes(P)), dtype=torch.uint8, device=dev)
 
         def run(g_tr_arg, d_unnorm_out, cam_out):
             with torch.cuda.device(dev):
-                rc = _lib.hsr_frame_prep_backward(
+                rc = _lib.hsr_frame_prep_backward_params(
                     P, S, int(transform_rots), rot_source, _p(means3D), _p(unnorm_rotations), _p(logit_opacities), _p(log_scales),
                     cam_unnorm_rots.data_ptr(), cam_trans.data_ptr(), frames, time_idx, w2c.data_ptr() if has_sil else None,
                     _p(g_means), _p(g_tr_arg), _p(g_rot), _p(g_op), _p(g_sc), _p(g_sil), _p(d_means), _p(d_unnorm_out), _p(d_logit),
-                    _p(d_ls), cam_out.data_ptr() if cam_out is not None else None,
-                    cam_out.data_ptr() + 16 if cam_out is not None else None, scratch.data_ptr(), scratch.numel(),
+                    _p(d_ls), _p(d_rots) if cam_out else None, _p(d_trans) if cam_out else None, scratch.data_ptr(), scratch.numel(),
                     torch.cuda.current_stream(dev).cuda_stream)
             if rc < 0:
                 _glue._fail(rc, "hsr_frame_prep_backward")
 
-        run(g_tr, d_unnorm, d_cam)
+        run(g_tr, d_unnorm, camera_grad)
         if gaussians_grad:
             out_means, out_unnorm = d_means, d_unnorm
         else:
@@ -148,16 +151,10 @@ class _FramePrep(torch.autograd.Function):
             if rot_source == ROT_PARAMS:
                 if g_tr is not None:
                     d_unnorm = torch.empty((P, 4), **o)
-                    run(None, d_unnorm, None)
+                    run(None, d_unnorm, False)
                 out_unnorm = d_unnorm
             else:
                 out_unnorm = None
-        d_rots = d_trans = None
-        if camera_grad:
-            d_rots = torch.zeros_like(cam_unnorm_rots)
-            d_trans = torch.zeros_like(cam_trans)
-            d_rots[0, :, time_idx] = d_cam[:4]
-            d_trans[0, :, time_idx] = d_cam[4:]
         return out_means, out_unnorm, d_logit, d_ls, d_rots, d_trans, None, None, None, None, None
 
 
@@ -237,7 +234,10 @@ def _bundle_of(params, transformed_gaussians, rot_source, w2c=None):
 
 def _means2D(params):
     # the reference's gradient sink for densification statistics (slam_helpers.py:137)
-    return torch.zeros_like(params['means3D'], requires_grad=True) + 0
+    # (the reference adds 0 to turn the zeros into a non-leaf whose .grad it retains; a view does the same without a kernel: the
+    # rasterizer never reads the values, it only returns this tensor's gradient)
+    z = torch.zeros_like(params['means3D'], requires_grad=True)
+    return z.view_as(z)
 
 
 def transformed_params2rendervar(params, transformed_gaussians):

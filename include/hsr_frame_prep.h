@@ -65,6 +65,18 @@ int hsr_frame_prep_backward(int P, int S, int transform_rots, int rot_source, co
                             float* dL_dmeans3D, float* dL_dunnorm_rotations, float* dL_dlogit_opacities, float* dL_dlog_scales,
                             float* dL_dcam_unnorm_rot, float* dL_dcam_tran, char* scratch, size_t scratch_bytes, void* stream);
 
+/* The same, with the pose gradients shaped like the parameters the reference optimises (scripts/hierslam.py:394-395):
+ * dL_dcam_unnorm_rots [4 * num_frames] and dL_dcam_trans [3 * num_frames], element (c, t) at c * num_frames + t — column
+ * `time_idx` receives the gradient, every other column is zeroed by the same launch (what autograd's slicing backward
+ * produces with a zero-fill and a strided copy per parameter). */
+int hsr_frame_prep_backward_params(int P, int S, int transform_rots, int rot_source, const float* means3D, const float* unnorm_rotations,
+                                   const float* logit_opacities, const float* log_scales, const float* cam_unnorm_rots,
+                                   const float* cam_trans, int num_frames, int time_idx, const float* w2c,
+                                   const float* dL_dout_means3D, const float* dL_dout_unnorm_rot, const float* dL_dout_rotations,
+                                   const float* dL_dout_opacities, const float* dL_dout_scales, const float* dL_dout_depth_sil,
+                                   float* dL_dmeans3D, float* dL_dunnorm_rotations, float* dL_dlogit_opacities, float* dL_dlog_scales,
+                                   float* dL_dcam_unnorm_rots, float* dL_dcam_trans, char* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

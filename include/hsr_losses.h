@@ -56,6 +56,19 @@ int hsr_loss_tree_ce(int K, int H, int W, int num_levels, const int* level_sizes
                      const int64_t* labels, int ignore_index, float* out_level_loss, float* out_grad, char* scratch,
                      size_t scratch_bytes, void* stream);
 
+/* The same loss in two passes, for an autograd node (hsr_utils/losses.py): the value pass counts the valid labels itself and writes no
+ * gradient — out_level_loss[l] as above, out_inv_count[l] = 1 / (pixels of level l whose label != ignore_index), both DEVICE float
+ * [num_levels]; the gradient pass writes out_grad = upstream[0] * d (sum_l level_weight[l] * loss_l) / d logits, where `upstream` is a
+ * DEVICE float (the node's incoming gradient; NULL = 1) and `inv_count` is what the value pass returned.  Scratch (value pass):
+ * hsr_loss_tree_ce_scratch_bytes(H, W) — block partials only, a few hundred KB. */
+size_t hsr_loss_tree_ce_scratch_bytes(int H, int W);
+int hsr_loss_tree_ce_value(int K, int H, int W, int num_levels, const int* level_sizes, const float* logits, const int64_t* labels,
+                           int ignore_index, float* out_level_loss, float* out_inv_count, char* scratch, size_t scratch_bytes,
+                           void* stream);
+int hsr_loss_tree_ce_grad(int K, int H, int W, int num_levels, const int* level_sizes, const float* level_weight, const float* logits,
+                          const int64_t* labels, int ignore_index, const float* inv_count, const float* upstream, float* out_grad,
+                          void* stream);
+
 /* Leaf head, fused: logits = Conv2d(K, C, kernel_size=1)(sem) (weight [C,K] = the conv's [C,K,1,1], bias [C];
  * scripts/hierslam.py:1756), loss = CrossEntropyLoss()(logits as [H*W, C], labels) (scripts/hierslam.py:976-983), and the
  * gradients d loss / d sem ([K,H,W]), d weight ([C,K]), d bias ([C]) — each may be NULL.  The [C,H,W] logits are never

@@ -47,7 +47,7 @@ def test_ctypes_signatures_match_header():
         fn = getattr(_C._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
     from hsr_utils import slam_helpers
-    for name in ("hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_scratch_bytes"):
+    for name in ("hsr_frame_prep_forward", "hsr_frame_prep_backward", "hsr_frame_prep_backward_params", "hsr_frame_prep_scratch_bytes"):
         fn = getattr(slam_helpers._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
     from hsr_utils import densify
@@ -59,7 +59,8 @@ def test_ctypes_signatures_match_header():
         fn = getattr(slam_external._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
     from hsr_utils import losses
-    for name in ("hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes"):
+    for name in ("hsr_loss_l1", "hsr_loss_ssim", "hsr_loss_tree_ce", "hsr_loss_tree_ce_value", "hsr_loss_tree_ce_grad", "hsr_loss_tree_ce_scratch_bytes",
+                 "hsr_loss_leaf_mlp_ce", "hsr_loss_scratch_bytes"):
         fn = getattr(losses._lib, name)
         assert len(fn.argtypes) == protos[name], (name, len(fn.argtypes), protos[name])
 

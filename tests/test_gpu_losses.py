@@ -273,3 +273,50 @@ def test_leaf_mlp_head_wide_falls_back_to_conv_plus_fused_ce():
     loss.backward()
     ref = torch.nn.functional.cross_entropy(mlp(sem.detach().unsqueeze(0)).squeeze(0).view(C, -1).permute(1, 0), lab.view(-1))
     assert abs(float(loss) - float(ref)) < 1e-5 and sem.grad is not None and mlp.weight.grad is not None
+
+
+def test_tree_ce_two_pass_form_matches_the_one_pass_entry_point_and_scales_by_the_upstream_gradient():
+    """hsr_loss_tree_ce_value / _grad (what the autograd node calls since round 4) against hsr_loss_tree_ce (value and gradient in one
+    pass, still exported): same level losses, same gradient; an upstream gradient g != 1 scales it inside the gradient pass; a level
+    wider than the 16 channels the kernel holds in registers takes its streaming path."""
+    import ctypes as C
+    from hsr_utils import losses as L
+    g = np.random.default_rng(17)
+    for sizes, K, H, W in (([2, 4, 6, 6, 8], 26, 37, 61), ([3, 21, 5], 31, 19, 33)):   # second: a 21-channel level
+        z = torch.tensor(g.normal(0, 3, (K, H, W)).astype(np.float32), device="cuda")
+        lab_np = np.stack([g.integers(0, n, (H, W)) for n in sizes]).astype(np.int64)
+        lab_np[1, :3] = -100
+        lab = torch.tensor(lab_np, device="cuda")
+        w = [1.0, 0.25, 2.0, 1.5, 0.5][:len(sizes)]
+        n = len(sizes)
+        csz, cw = (C.c_int * n)(*sizes), (C.c_float * n)(*w)
+        out1, grad1 = torch.empty(n, device="cuda"), torch.empty_like(z)
+        sc = torch.empty(int(L._lib.hsr_loss_scratch_bytes(K, H, W)), dtype=torch.uint8, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        assert L._lib.hsr_loss_tree_ce(K, H, W, n, csz, cw, z.data_ptr(), lab.data_ptr(), -100, out1.data_ptr(), grad1.data_ptr(),
+                                       sc.data_ptr(), sc.numel(), s) == 0
+        zz = z.clone().requires_grad_(True)
+        total, levels = L.tree_cross_entropy(zz, lab, sizes, weights=w, return_levels=True)
+        (3.5 * total).backward()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(levels.cpu().numpy(), out1.cpu().numpy(), rtol=2e-6)
+        assert _relmax(zz.grad.cpu().numpy(), 3.5 * grad1.cpu().numpy()) < GRAD_TOL
+
+
+def test_weighted_sum_is_the_python_arithmetic_it_replaces():
+    from hsr_utils import losses as L
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.rand(3, 40, 56, generator=g).cuda().requires_grad_(True), torch.rand(3, 40, 56, generator=g).cuda()
+    ref = 0.5 * (0.8 * L.l1_loss_v1(a, b) + 0.2 * (1.0 - L.calc_ssim(a, b)))
+    ref.backward()
+    g_ref, a.grad = a.grad.clone(), None
+    got = L.weighted_sum((L.l1_loss_v1(a, b), L.calc_ssim(a, b)), (0.4, -0.1), constant=0.1)
+    got.backward()
+    assert abs(float(got) - float(ref)) < 1e-6
+    assert _relmax(a.grad.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
+    a.grad = None
+    m = L.mapping_image_loss(a, b)
+    m.backward()
+    assert abs(float(m) - 2.0 * float(ref)) < 2e-6 and _relmax(a.grad.cpu().numpy(), 2.0 * g_ref.cpu().numpy()) < 1e-6
+    with pytest.raises(RuntimeError, match="weighted_sum"):
+        L.weighted_sum((got,), (1.0, 2.0))

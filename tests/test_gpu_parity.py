@@ -866,3 +866,34 @@ def test_backward_twice_through_a_retained_graph():
         finally:
             dgr.set_async_forward(prev)
         _same_up_to_atomics_order({n: 2.0 * v for n, v in once.items()}, {n: leaf[n].grad for n in leaf})
+
+
+@pytest.mark.parametrize("used", [("depth", "color"), ("semantic",), ("opacity",)])
+def test_outputs_the_loss_does_not_use_cost_no_zero_filled_maps(used):
+    """autograd would hand backward() a freshly zero-filled map for every output the loss does not touch (a K x H x W fill per tracking
+    iteration); the node asks for None instead and substitutes cached, never-written zero maps.  Gradients = the oracle's with zero upstream
+    gradients for the unused outputs; the cached maps are still all zero afterwards."""
+    import diff_gaussian_rasterization as D
+    from diff_gaussian_rasterization import GaussianRasterizer_semantic
+    from harness import _cam_to
+    W, H, P, K = 128, 80, 2000, 16
+    cam, sc, up = scenes.build(W, H, P, K, seed=13, kind="slam", scale_mult=3.0)
+    dev = torch.device("cuda:0")
+    leaf = {n: sc[n].to(dev).clone().requires_grad_(True) for n in ("means3D", "opacities", "colors_precomp", "scales", "rotations", "semantics_precomp")}
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    color, radii, sem, depth, median, opacity = GaussianRasterizer_semantic(_cam_to(cam, dev))(means2D=means2D, **leaf)
+    outs = dict(color=color, semantic=sem, depth=depth, median=median, opacity=opacity)
+    loss = sum((outs[n] * up[n].to(dev)).sum() for n in used)
+    loss.backward()
+    torch.cuda.synchronize()
+    up0 = {n: (v if n in used else torch.zeros_like(v)) for n, v in up.items()}
+    _, go, so = run_oracle(cam, sc, up0, semantic=True, variant="sr")
+    import harness
+    for n in leaf:
+        g = leaf[n].grad.cpu().numpy()
+        assert_close("grad %s (loss on %s only)" % (n, "+".join(used)), g, go[n], allowance=harness.tie_allowance("grad " + n, so, g.shape, "gauss"))
+    so.free()
+    cached = [z for (d, shape), z in D._zero_maps.items() if d == dev]
+    assert cached, "no cached zero map was used"
+    for z in cached:
+        assert not z.any(), "a cached zero map was written to"

@@ -73,9 +73,13 @@ def measure(P=500000, W=1200, H=680, iters=20):
         im, radius, sem, depth, med, opac = GaussianRasterizer_semantic(raster_settings=cam)(**rv)
         mask = ((gt_d > 0) & ~torch.isnan(depth)).detach()
         if fused:
-            loss = 0.5 * L.mapping_image_loss(im, gt_im) + L.masked_l1(depth, gt_d, mask, "mean") + 0.1 * L.tree_cross_entropy(sem, lab, sizes)
+            # the weighted dictionary sum of scripts/hierslam.py:1003-1016 as one node (L.weighted_sum) instead of Python arithmetic on 0-dim tensors
+            terms = [L.l1_loss_v1(im, gt_im), L.calc_ssim(im, gt_im), L.masked_l1(depth, gt_d, mask, "mean"), L.tree_cross_entropy(sem, lab, sizes)]
+            weights = [0.5 * 0.8, -0.5 * 0.2, 1.0, 0.1]
             if leaf:
-                loss = loss + 0.5 * L.leaf_mlp_cross_entropy(sem, mlp, leaf_lab)
+                terms.append(L.leaf_mlp_cross_entropy(sem, mlp, leaf_lab))
+                weights.append(0.5)
+            loss = L.weighted_sum(terms, weights, constant=0.5 * 0.2)
         else:
             ce, b = 0.0, 0
             celoss = torch.nn.CrossEntropyLoss()
@@ -114,8 +118,10 @@ def measure(P=500000, W=1200, H=680, iters=20):
             rv = {k: (v if k in ("means3D", "means2D") or v is None else v.detach()) for k, v in rv.items()}
         im, radius, sem, depth, med, opac = GaussianRasterizer_semantic(raster_settings=cam)(**rv)
         mask = ((gt_d > 0) & ~torch.isnan(depth) & (opac > 0.99)).detach()
-        if fused:
+        if fused and os.environ.get("HSR_ITER_PLAIN_SUM"):
             loss = L.masked_l1(depth, gt_d, mask, "sum") + 0.5 * L.masked_l1(im, gt_im, mask, "sum")
+        elif fused:
+            loss = L.weighted_sum((L.masked_l1(depth, gt_d, mask, "sum"), L.masked_l1(im, gt_im, mask, "sum")), (1.0, 0.5))
         else:
             loss = torch.abs(gt_d - depth)[mask].sum() + 0.5 * torch.abs(gt_im - im)[torch.tile(mask, (3, 1, 1))].sum()
         loss.backward()
@@ -135,6 +141,10 @@ def measure(P=500000, W=1200, H=680, iters=20):
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / iters * 1e3)
         return best
+    if os.environ.get("HSR_ITER_ONLY") == "mapping":     # for a kernel trace of the fused mapping iteration alone (tools/ktrace_iter.sh)
+        return {"fused_ms": timeit(True)}
+    if os.environ.get("HSR_ITER_ONLY") == "tracking":
+        return {"tracking_fused_map_detached_ms": time_tracking(True, True)}
     lf, le = float(iteration(True).detach()), float(iteration(False).detach())
     # the opt-in non-blocking forward (diff_gaussian_rasterization.set_async_forward): the host no longer waits for num_rendered in
     # every frame, so the Python side of the iteration overlaps the device side of the previous one
