@@ -247,6 +247,7 @@ int64_t binning_hint(int64_t device_index, int64_t P, int64_t W, int64_t H, int6
     std::lock_guard<std::mutex> lock(g_hint_mutex);
     const auto key = std::make_tuple((int)device_index, P, W, H);
     if (set_to == -2) { g_binning_hint.erase(key); return -1; }
+    if (set_to == -3) { g_binning_hint.clear(); return -1; }   // forget every size (tests: each case starts cold)
     if (set_to >= 0) g_binning_hint[key] = set_to;
     auto it = g_binning_hint.find(key);
     return it == g_binning_hint.end() ? -1 : it->second;

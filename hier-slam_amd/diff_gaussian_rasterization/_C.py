@@ -156,6 +156,12 @@ class _HintMap(dict):
     def get(self, key, default=None):
         return self[key] if key in self else default
 
+    def clear(self):
+        if _ext is None:
+            dict.clear(self)
+        else:
+            self._e((0, 0, 0, 0), -3)
+
     def pop(self, key, *default):
         if key in self:
             v = self[key]

@@ -249,6 +249,8 @@ def test_ctypes_glue_matches_too():
 
 def test_compiled_glue_is_loaded():
     from diff_gaussian_rasterization import _C
+    if os.environ.get("HSR_GLUE") == "ctypes":
+        pytest.skip("HSR_GLUE=ctypes asks for the pure-Python glue")
     assert _C._ext is not None, "diff_gaussian_rasterization._hsr_torch is not built (python hier-slam_amd/csrc/build_torch_ext.py)"
 
 

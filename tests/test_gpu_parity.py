@@ -251,6 +251,9 @@ def test_speculative_forward_and_its_fallback_agree_with_the_oracle(monkeypatch)
     to 1e-4 (_compare), and num_rendered must be the same."""
     import torch
     from diff_gaussian_rasterization import _C
+    if os.environ.get("HSR_ASYNC_FORWARD"):
+        pytest.skip("the blocking forward's grow-and-rerun fallback: with the non-blocking forward forced on, a hint of 1 is the overflow that "
+                    "mode reports by design (test_non_blocking_forward_runs_ahead_and_fails_loudly_when_the_buffer_was_too_small)")
     W, H, P, K = 203, 131, 3000, 26
     cam, sc, up = scenes.build(W, H, P, K, seed=5, kind="slam")
     key = (torch.device("cuda:0").index, P, W, H)
