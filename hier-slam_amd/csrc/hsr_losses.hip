@@ -485,6 +485,7 @@ constexpr int LM_MAX_CT = 8;        // class tiles of 16: C <= 128
 constexpr int LM_PANEL = 64 * 17;   // floats per wave: max(16 * 66, 64 * 17)
 constexpr int LM_STRIDE = 66;
 typedef float lm_f32x4 __attribute__((ext_vector_type(4)));
+typedef float lm_f32x2 __attribute__((ext_vector_type(2)));
 
 // KU: input columns actually multiplied (K channels + the bias input, rounded up to 4); CT: class tiles in use (<= 8)
 template <int KU, int MAXCT>
@@ -542,9 +543,12 @@ __global__ void __launch_bounds__(256, 3) leaf_mlp_ce_kernel(const float* __rest
         float m2 = -INFINITY, sum = 0.f, picked = 0.f;
         {
             auto class1 = [&](int c, const float (&w)[KU]) {
-                float z = 0.f;
+                // two interleaved partial sums: the pairs (w[2j], w[2j+1]) x (sv[2j], sv[2j+1]) become v_pk_fma_f32 — half the
+                // instructions of a 28-deep v_fmac chain, and the kernel's time is the instructions it issues
+                lm_f32x2 zz = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < KU; k++) z = fmaf(w[k], sv[k], z);
+                for (int k = 0; k < KU; k += 2) zz = __builtin_elementwise_fma(lm_f32x2{w[k], w[k + 1]}, lm_f32x2{sv[k], sv[k + 1]}, zz);
+                const float z = zz.x + zz.y;
                 picked = c == lab ? z : picked;
                 const float z2 = z * L2E;
                 const float nm = fmaxf(m2, z2);
@@ -575,9 +579,10 @@ __global__ void __launch_bounds__(256, 3) leaf_mlp_ce_kernel(const float* __rest
         for (int k = 0; k < LM_KP; k++) ds[k] = 0.f;
         {
             auto class2 = [&](int c, const float (&w)[KU]) {
-                float z = 0.f;
+                lm_f32x2 zz = {0.f, 0.f};   // as in pass 1 (the same summation order: the softmax of pass 2 is that of pass 1's log-sum-exp)
 #pragma unroll
-                for (int k = 0; k < KU; k++) z = fmaf(w[k], sv[k], z);
+                for (int k = 0; k < KU; k += 2) zz = __builtin_elementwise_fma(lm_f32x2{w[k], w[k + 1]}, lm_f32x2{sv[k], sv[k + 1]}, zz);
+                const float z = zz.x + zz.y;
                 // rows >= C of the packed weights are zero: z = 0 there, and the class must not contribute
                 const float g = c < C ? (__builtin_amdgcn_exp2f(fmaf(z, L2E, -lse2)) - (c == lab ? 1.f : 0.f)) * gscale : 0.f;
 #pragma unroll

@@ -143,6 +143,8 @@ def measure(P=500000, W=1200, H=680, iters=20):
         return best
     if os.environ.get("HSR_ITER_ONLY") == "mapping":     # for a kernel trace of the fused mapping iteration alone (tools/ktrace_iter.sh)
         return {"fused_ms": timeit(True)}
+    if os.environ.get("HSR_ITER_ONLY") == "leaf":
+        return {"with_leaf_head_fused_ms": timeit(True, True)}
     if os.environ.get("HSR_ITER_ONLY") == "tracking":
         return {"tracking_fused_map_detached_ms": time_tracking(True, True)}
     lf, le = float(iteration(True).detach()), float(iteration(False).detach())
