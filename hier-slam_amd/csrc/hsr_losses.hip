@@ -337,8 +337,12 @@ template <bool GRAD>
 __global__ __launch_bounds__(LB) void tree_ce2_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int N, int K,
                                                       Levels lv, int ignore_index, const float* __restrict__ inv_count,
                                                       const float* __restrict__ upstream, float* __restrict__ grad,
-                                                      float* __restrict__ partials /* [nblk][2 * MAX_LEVELS]: loss sums, then counts */)
+                                                      float* __restrict__ partials /* [nblk][2 * MAX_LEVELS]: loss sums, then counts */,
+                                                      const float* __restrict__ add_grad, const float* __restrict__ add_scale, float add_host_scale)
 {
+    // GRAD: out = tree part + add_grad * (add_scale[0] * add_host_scale) — another head's stashed gradient of the same map (the leaf head's)
+    // joins here instead of costing its own `stash * g` pass and autograd's add of the two K x H x W maps
+    const float as = (GRAD && add_grad) ? (add_scale ? add_scale[0] : 1.0f) * add_host_scale : 0.f;
     __shared__ float s_part[4][2 * HSR_LOSS_MAX_LEVELS];
     const int i = blockIdx.x * LB + threadIdx.x;
     const bool live = i < N;
@@ -373,7 +377,11 @@ __global__ __launch_bounds__(LB) void tree_ce2_kernel(const float* __restrict__ 
                 if (live) {
 #pragma unroll
                     for (int c = 0; c < CE_REG; c++)
-                        if (c < n) grad[(size_t)(b + c) * N + p] = (z[c] * inv_s - (c == lab ? 1.f : 0.f)) * sc;
+                        if (c < n) {
+                            const size_t gi = (size_t)(b + c) * N + p;
+                            const float tv = (z[c] * inv_s - (c == lab ? 1.f : 0.f)) * sc;
+                            grad[gi] = add_grad ? fmaf(add_grad[gi], as, tv) : tv;
+                        }
                 }
             } else {
                 loss = valid ? (m + logf(s)) - picked : 0.f;
@@ -393,7 +401,9 @@ __global__ __launch_bounds__(LB) void tree_ce2_kernel(const float* __restrict__ 
                 if (live)
                     for (int c = 0; c < n; c++) {
                         const float z = logits[(size_t)(b + c) * N + p];
-                        grad[(size_t)(b + c) * N + p] = (expf(z - m) * inv_s - (c == lab ? 1.f : 0.f)) * sc;
+                        const size_t gi = (size_t)(b + c) * N + p;
+                        const float tv = (expf(z - m) * inv_s - (c == lab ? 1.f : 0.f)) * sc;
+                        grad[gi] = add_grad ? fmaf(add_grad[gi], as, tv) : tv;
                     }
             } else {
                 loss = valid ? (m + logf(s)) - picked : 0.f;
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(LB) void tree_ce2_kernel(const float* __restrict__ 
     }
     if (GRAD) {
         if (live)
-            for (int c = covered_end; c < K; c++) grad[(size_t)c * N + p] = 0.f;   // channels behind the last level
+            for (int c = covered_end; c < K; c++) grad[(size_t)c * N + p] = add_grad ? add_grad[(size_t)c * N + p] * as : 0.f;   // channels behind the last level
         return;
     }
     // one reduction for all levels: wave sums, then the four waves in a fixed order (counts are exact in fp32: <= 256 per block)
@@ -658,21 +668,31 @@ __global__ __launch_bounds__(256) void leaf_pack_weights_kernel(const float* __r
 
 // d_weight[c][k], d_bias[c] = fixed-order sum over the workgroup partials (double): 32 outputs x 8 partial-groups per
 // workgroup, groups combined through LDS in index order
-__global__ __launch_bounds__(256) void leaf_finish_dw_kernel(const float* __restrict__ part_dw, int nblk, int per, int K, int C,
-                                                             float* __restrict__ d_weight, float* __restrict__ d_bias)
+// (32 partial-groups of a 1 024-thread block, four loads in flight per thread: with 8 groups walking 96 partials each, one after the
+// other, the launch took 30 us for 11 MB)
+constexpr int LFD_T = 1024, LFD_G = LFD_T / 32;
+__global__ __launch_bounds__(LFD_T) void leaf_finish_dw_kernel(const float* __restrict__ part_dw, int nblk, int per, int K, int C,
+                                                               float* __restrict__ d_weight, float* __restrict__ d_bias)
 {
-    __shared__ double s_acc[8][33];
+    __shared__ double s_acc[LFD_G][33];
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + o;
     double acc = 0.0;
-    if (i < per)
-        for (int b = grp; b < nblk; b += 8) acc += (double)part_dw[(size_t)b * per + i];
+    if (i < per) {
+        int b = grp;
+        for (; b + 3 * LFD_G < nblk; b += 4 * LFD_G) {
+            const float v0 = part_dw[(size_t)b * per + i], v1 = part_dw[(size_t)(b + LFD_G) * per + i];
+            const float v2 = part_dw[(size_t)(b + 2 * LFD_G) * per + i], v3 = part_dw[(size_t)(b + 3 * LFD_G) * per + i];
+            acc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < nblk; b += LFD_G) acc += (double)part_dw[(size_t)b * per + i];
+    }
     s_acc[grp][o] = acc;
     __syncthreads();
     if (grp != 0 || i >= per) return;
     double tot = 0.0;
 #pragma unroll
-    for (int g2 = 0; g2 < 8; g2++) tot += s_acc[g2][o];
+    for (int g2 = 0; g2 < LFD_G; g2++) tot += s_acc[g2][o];
     const int c = i / LM_KP, k = i - c * LM_KP;
     if (c >= C || k > K) return;
     if (k < K) { if (d_weight) d_weight[(size_t)c * K + k] = (float)tot; }
@@ -890,7 +910,7 @@ extern "C" int hsr_loss_tree_ce_value(int K, int H, int W, int num_levels, const
     rc = check_scratch("loss_tree_ce_value", scratch, scratch_bytes, hsr_loss_tree_ce_scratch_bytes(H, W) - 256);
     if (rc != HSR_OK) return rc;
     float* partials = reinterpret_cast<float*>(scratch);
-    tree_ce2_kernel<false><<<nb, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, nullptr, nullptr, nullptr, partials);
+    tree_ce2_kernel<false><<<nb, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, nullptr, nullptr, nullptr, partials, nullptr, nullptr, 0.f);
     tree_ce_finish_kernel<<<1, CEF_T, 0, stream>>>(partials, nb, num_levels, out_level_loss, out_inv_count);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
@@ -898,7 +918,8 @@ extern "C" int hsr_loss_tree_ce_value(int K, int H, int W, int num_levels, const
 
 extern "C" int hsr_loss_tree_ce_grad(int K, int H, int W, int num_levels, const int* level_sizes, const float* level_weight,
                                      const float* logits, const int64_t* labels, int ignore_index, const float* inv_count,
-                                     const float* upstream, float* out_grad, void* stream_)
+                                     const float* upstream, const float* add_grad, const float* add_scale, float add_host_scale,
+                                     float* out_grad, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     Levels lv;
@@ -909,7 +930,8 @@ extern "C" int hsr_loss_tree_ce_grad(int K, int H, int W, int num_levels, const 
         return HSR_ERR_INVALID_ARGUMENT;
     }
     const int N = H * W;
-    tree_ce2_kernel<true><<<(N + LB - 1) / LB, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, inv_count, upstream, out_grad, nullptr);
+    tree_ce2_kernel<true><<<(N + LB - 1) / LB, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, inv_count, upstream, out_grad, nullptr, add_grad,
+                                                                add_scale, add_host_scale);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
 }
@@ -961,7 +983,7 @@ extern "C" int hsr_loss_leaf_mlp_ce(int K, int C, int H, int W, const float* sem
 #undef HSR_LEAF_LAUNCH
     finish_kernel<<<1, LB, 0, stream>>>(part_loss, nblk, 1, 1, inv, 1.0f, out_loss);
     if (d_weight || d_bias)
-        leaf_finish_dw_kernel<<<(CT * 16 * LM_KP + 31) / 32, 256, 0, stream>>>(part_dw, nblk, CT * 16 * LM_KP, K, C, d_weight, d_bias);
+        leaf_finish_dw_kernel<<<(CT * 16 * LM_KP + 31) / 32, LFD_T, 0, stream>>>(part_dw, nblk, CT * 16 * LM_KP, K, C, d_weight, d_bias);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
 }

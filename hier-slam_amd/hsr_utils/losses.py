@@ -34,7 +34,7 @@ _lib.hsr_loss_tree_ce_scratch_bytes.argtypes = [_ci, _ci]
 _lib.hsr_loss_tree_ce_value.restype = _ci
 _lib.hsr_loss_tree_ce_value.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), _vp, _vp, _ci, _vp, _vp, _vp, _sz, _vp]
 _lib.hsr_loss_tree_ce_grad.restype = _ci
-_lib.hsr_loss_tree_ce_grad.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), C.POINTER(C.c_float), _vp, _vp, _ci, _vp, _vp, _vp, _vp]
+_lib.hsr_loss_tree_ce_grad.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), C.POINTER(C.c_float), _vp, _vp, _ci, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp]
 _lib.hsr_loss_leaf_mlp_ce.restype = _ci
 _lib.hsr_loss_leaf_mlp_ce.argtypes = [_ci, _ci, _ci, _ci] + [_vp] * 4 + [_ci] + [_vp] * 5 + [_sz, _vp]
 
@@ -166,7 +166,7 @@ class _TreeCE(torch.autograd.Function):
         grad = torch.empty_like(z)
         with torch.cuda.device(dev):
             rc = _lib.hsr_loss_tree_ce_grad(K, H, W, L, sizes, w, z.data_ptr(), lab.data_ptr(), ignore_index, inv.data_ptr(), g.data_ptr(),
-                                            grad.data_ptr(), _stream(dev))
+                                            None, None, 0.0, grad.data_ptr(), _stream(dev))
         if rc < 0:
             _glue._fail(rc, "hsr_loss_tree_ce_grad")
         return grad.view(shape), None, None, None, None
@@ -278,6 +278,102 @@ class _LeafMLP(torch.autograd.Function):
     def backward(ctx, g):
         ds, dw, db = ctx.grads
         return (None if ds is None else ds * g, None if dw is None else dw * g, None if db is None else db * g, None, None)
+
+
+class _SemanticHeads(torch.autograd.Function):
+    """losses['sem'] of get_loss_semantic_mlp once the leaf head is on (scripts/hierslam.py:963-983): w_tree * sum over the tree levels of the
+    per-level cross-entropy + w_leaf * cross-entropy of the 1x1-conv leaf head — as ONE node over the semantic map.  Forward: the tree value
+    pass and the fused leaf kernel (which stashes d leaf / d sem).  Backward: ONE pass writes d total / d sem — the tree gradient pass takes
+    the leaf head's stashed gradient along (hsr_loss_tree_ce_grad, add_grad) instead of a `stash * g` pass and autograd's add of two
+    K x H x W maps."""
+
+    @staticmethod
+    def forward(ctx, sem, weight, bias, labels, level_sizes, w_tree, w_leaf, ignore_index):
+        z = _chw(sem, "im_semantic")
+        K, H, W = z.shape
+        dev = z.device
+        L = len(level_sizes)
+        lab = labels.reshape(-1, H, W)
+        if lab.shape[0] < L + 1:
+            raise RuntimeError("hsr_utils.losses: %d label planes for %d tree levels + the leaf level" % (lab.shape[0], L))
+        lab = lab.to(device=dev, dtype=torch.int64).contiguous()
+        tree_lab, leaf_lab = lab[:L], lab[-1]
+        wt = _dev2(weight.reshape(weight.shape[0], -1), "weight")
+        Cc = wt.shape[0]
+        if wt.shape[1] != K or bias.numel() != Cc:
+            raise RuntimeError("hsr_utils.losses: weight %s / bias %s do not match %d input channels" % (tuple(weight.shape), tuple(bias.shape), K))
+        b = _dev2(bias.reshape(-1), "bias")
+        sizes = (_ci * L)(*[int(s) for s in level_sizes])
+        levels = torch.empty(L, dtype=torch.float32, device=dev)
+        inv = torch.empty(L, dtype=torch.float32, device=dev)
+        leaf = torch.empty(1, dtype=torch.float32, device=dev)
+        need = (sem.requires_grad, weight.requires_grad, bias.requires_grad)
+        d_sem = torch.empty_like(z) if need[0] else None
+        d_w = torch.empty_like(wt) if (need[1] or need[2]) else None
+        d_b = torch.empty_like(b) if (need[1] or need[2]) else None
+        sc1 = torch.empty(int(_lib.hsr_loss_tree_ce_scratch_bytes(H, W)), dtype=torch.uint8, device=dev)
+        sc2 = _scratch(K, H, W, dev)
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_tree_ce_value(K, H, W, L, sizes, z.data_ptr(), tree_lab.data_ptr(), int(ignore_index), levels.data_ptr(),
+                                             inv.data_ptr(), sc1.data_ptr(), sc1.numel(), _stream(dev))
+            if rc < 0:
+                _glue._fail(rc, "hsr_loss_tree_ce_value")
+            rc = _lib.hsr_loss_leaf_mlp_ce(K, Cc, H, W, z.data_ptr(), wt.data_ptr(), b.data_ptr(), leaf_lab.data_ptr(), int(ignore_index),
+                                           leaf.data_ptr(), None if d_sem is None else d_sem.data_ptr(), None if d_w is None else d_w.data_ptr(),
+                                           None if d_b is None else d_b.data_ptr(), sc2.data_ptr(), sc2.numel(), _stream(dev))
+            if rc < 0:
+                _glue._fail(rc, "hsr_loss_leaf_mlp_ce")
+        ctx.want = need
+        if need[0]:
+            ctx.save_for_backward(z, tree_lab, inv)
+        ctx.meta = (K, H, W, L, sizes, float(w_tree), float(w_leaf), int(ignore_index), tuple(sem.shape))
+        ctx.stash = (d_sem, None if d_w is None else d_w.view(weight.shape), None if d_b is None else d_b.view(bias.shape))
+        ctx.mark_non_differentiable(levels)
+        total = levels.sum() * float(w_tree) + leaf[0] * float(w_leaf)
+        return total, levels, leaf[0].detach()
+
+    @staticmethod
+    def backward(ctx, g, _g_levels, _g_leaf):
+        K, H, W, L, sizes, w_tree, w_leaf, ignore_index, shape = ctx.meta
+        d_sem, d_w, d_b = ctx.stash
+        if g is None:
+            return (None,) * 8
+        out_sem = None
+        if ctx.want[0]:
+            z, tree_lab, inv = ctx.saved_tensors
+            dev = z.device
+            gg = g.to(device=dev, dtype=torch.float32).contiguous()
+            wl = (C.c_float * L)(*([w_tree] * L))
+            grad = torch.empty_like(z)
+            with torch.cuda.device(dev):
+                rc = _lib.hsr_loss_tree_ce_grad(K, H, W, L, sizes, wl, z.data_ptr(), tree_lab.data_ptr(), ignore_index, inv.data_ptr(),
+                                                gg.data_ptr(), d_sem.data_ptr(), gg.data_ptr(), w_leaf, grad.data_ptr(), _stream(dev))
+            if rc < 0:
+                _glue._fail(rc, "hsr_loss_tree_ce_grad")
+            out_sem = grad.view(shape)
+        gl = g * w_leaf
+        return (out_sem, None if (d_w is None or not ctx.want[1]) else d_w * gl, None if (d_b is None or not ctx.want[2]) else d_b * gl,
+                None, None, None, None, None)
+
+
+def semantic_loss_mlp(im_semantic, labels, num_semantic, mlp, weight_sem=(1.0, 1.0), ignore_index=-100, return_parts=False):
+    """losses['sem'] of the reference's get_loss_semantic_mlp with the leaf head on (scripts/hierslam.py:963-983):
+        weight_sem[0] * sum_l CrossEntropyLoss(level l of the tree) + weight_sem[1] * CrossEntropyLoss(MLP_func(im_semantic), leaf labels)
+    labels: [len(num_semantic) + 1, H, W], the last plane the leaf labels (curr_data['semantic_label_gt'] as the reference holds it).
+    One autograd node; gradients to im_semantic, mlp.weight, mlp.bias.  Heads wider than the fused leaf kernel takes fall back to the two
+    separate heads.  return_parts: also the per-level tree losses and the leaf loss (values, no gradient path)."""
+    weight, bias = (mlp.weight, mlp.bias) if hasattr(mlp, "weight") else mlp
+    K = im_semantic.shape[-3]
+    if K > LEAF_MAX_K or weight.shape[0] > LEAF_MAX_C:
+        L = len(num_semantic)
+        lab = labels.reshape(-1, *im_semantic.shape[-2:])
+        tree, levels = tree_cross_entropy(im_semantic, lab[:L], num_semantic, None, ignore_index, return_levels=True)
+        leaf = leaf_mlp_cross_entropy(im_semantic, mlp, lab[-1], ignore_index)
+        total = weighted_sum((tree, leaf), (float(weight_sem[0]), float(weight_sem[1])))
+        return (total, levels, leaf.detach()) if return_parts else total
+    total, levels, leaf = _SemanticHeads.apply(im_semantic, weight, bias, labels, tuple(num_semantic), float(weight_sem[0]), float(weight_sem[1]),
+                                               ignore_index)
+    return (total, levels, leaf) if return_parts else total
 
 
 def _dev2(t, what):

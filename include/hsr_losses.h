@@ -59,15 +59,18 @@ int hsr_loss_tree_ce(int K, int H, int W, int num_levels, const int* level_sizes
 /* The same loss in two passes, for an autograd node (hsr_utils/losses.py): the value pass counts the valid labels itself and writes no
  * gradient — out_level_loss[l] as above, out_inv_count[l] = 1 / (pixels of level l whose label != ignore_index), both DEVICE float
  * [num_levels]; the gradient pass writes out_grad = upstream[0] * d (sum_l level_weight[l] * loss_l) / d logits, where `upstream` is a
- * DEVICE float (the node's incoming gradient; NULL = 1) and `inv_count` is what the value pass returned.  Scratch (value pass):
+ * DEVICE float (the node's incoming gradient; NULL = 1) and `inv_count` is what the value pass returned.  `add_grad` ([K,H,W] or NULL):
+ * another head's gradient with respect to the same map (the leaf head's stashed d loss / d sem) joins in the same pass,
+ * out_grad += add_grad * add_scale[0] * add_host_scale (`add_scale`: DEVICE float or NULL = 1) — instead of a `stash * g` pass of its own and
+ * autograd's add of two K x H x W maps.  Scratch (value pass):
  * hsr_loss_tree_ce_scratch_bytes(H, W) — block partials only, a few hundred KB. */
 size_t hsr_loss_tree_ce_scratch_bytes(int H, int W);
 int hsr_loss_tree_ce_value(int K, int H, int W, int num_levels, const int* level_sizes, const float* logits, const int64_t* labels,
                            int ignore_index, float* out_level_loss, float* out_inv_count, char* scratch, size_t scratch_bytes,
                            void* stream);
 int hsr_loss_tree_ce_grad(int K, int H, int W, int num_levels, const int* level_sizes, const float* level_weight, const float* logits,
-                          const int64_t* labels, int ignore_index, const float* inv_count, const float* upstream, float* out_grad,
-                          void* stream);
+                          const int64_t* labels, int ignore_index, const float* inv_count, const float* upstream, const float* add_grad,
+                          const float* add_scale, float add_host_scale, float* out_grad, void* stream);
 
 /* Leaf head, fused: logits = Conv2d(K, C, kernel_size=1)(sem) (weight [C,K] = the conv's [C,K,1,1], bias [C];
  * scripts/hierslam.py:1756), loss = CrossEntropyLoss()(logits as [H*W, C], labels) (scripts/hierslam.py:976-983), and the

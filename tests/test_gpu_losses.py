@@ -320,3 +320,29 @@ def test_weighted_sum_is_the_python_arithmetic_it_replaces():
     assert abs(float(m) - 2.0 * float(ref)) < 2e-6 and _relmax(a.grad.cpu().numpy(), 2.0 * g_ref.cpu().numpy()) < 1e-6
     with pytest.raises(RuntimeError, match="weighted_sum"):
         L.weighted_sum((got,), (1.0, 2.0))
+
+
+def test_semantic_loss_mlp_is_the_two_heads_it_fuses():
+    """L.semantic_loss_mlp (tree levels + leaf head as one node, the leaf head's stashed gradient riding in the tree gradient pass) against
+    the two separate heads composed with Python arithmetic: value, d sem, d weight, d bias, with an upstream gradient != 1."""
+    from hsr_utils import losses as L
+    g = torch.Generator().manual_seed(11)
+    sizes, K, Cc, H, W = [2, 4, 6, 6, 8], 26, 102, 45, 77
+    sem = (torch.randn(K, H, W, generator=g) * 2).cuda()
+    mlp = torch.nn.Conv2d(K, Cc, kernel_size=1).cuda()
+    lab = torch.stack([torch.randint(0, n, (H, W), generator=g) for n in sizes] + [torch.randint(0, Cc, (H, W), generator=g)]).cuda()
+    lab[1, :2] = -100
+    lab[-1, 5:7] = -100
+    a = sem.clone().requires_grad_(True)
+    ref = 0.1 * L.tree_cross_entropy(a, lab[:5], sizes) + 0.5 * L.leaf_mlp_cross_entropy(a, mlp, lab[-1])
+    (2.5 * ref).backward()
+    want = (a.grad.clone(), mlp.weight.grad.clone(), mlp.bias.grad.clone())
+    mlp.weight.grad = mlp.bias.grad = None
+    b = sem.clone().requires_grad_(True)
+    got, levels, leaf = L.semantic_loss_mlp(b, lab, sizes, mlp, weight_sem=(0.1, 0.5), return_parts=True)
+    (2.5 * got).backward()
+    torch.cuda.synchronize()
+    assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert abs(float(0.1 * levels.sum() + 0.5 * leaf) - float(got)) <= 2e-6 * abs(float(got))
+    for name, x, y in (("d sem", b.grad, want[0]), ("d weight", mlp.weight.grad, want[1]), ("d bias", mlp.bias.grad, want[2])):
+        assert _relmax(x.cpu().numpy(), y.cpu().numpy()) < 2e-6, name

@@ -42,6 +42,7 @@ def measure(P=500000, W=1200, H=680, iters=20):
     lab = torch.stack([torch.randint(0, n, (H, W), generator=g) for n in sizes]).cuda()
     mlp = torch.nn.Conv2d(K, 102, kernel_size=1).cuda()          # MLP_func, scripts/hierslam.py:1756
     leaf_lab = torch.randint(0, 102, (H, W), generator=g).cuda()
+    lab_with_leaf = torch.cat((lab, leaf_lab[None]), 0)
     w1 = torch.tensor([np.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
     w1 = (w1 / w1.sum()).unsqueeze(1)
     win = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0).expand(3, 1, 11, 11).contiguous().cuda()
@@ -74,11 +75,12 @@ def measure(P=500000, W=1200, H=680, iters=20):
         mask = ((gt_d > 0) & ~torch.isnan(depth)).detach()
         if fused:
             # the weighted dictionary sum of scripts/hierslam.py:1003-1016 as one node (L.weighted_sum) instead of Python arithmetic on 0-dim tensors
-            terms = [L.l1_loss_v1(im, gt_im), L.calc_ssim(im, gt_im), L.masked_l1(depth, gt_d, mask, "mean"), L.tree_cross_entropy(sem, lab, sizes)]
-            weights = [0.5 * 0.8, -0.5 * 0.2, 1.0, 0.1]
-            if leaf:
-                terms.append(L.leaf_mlp_cross_entropy(sem, mlp, leaf_lab))
-                weights.append(0.5)
+            terms = [L.l1_loss_v1(im, gt_im), L.calc_ssim(im, gt_im), L.masked_l1(depth, gt_d, mask, "mean")]
+            weights = [0.5 * 0.8, -0.5 * 0.2, 1.0, 1.0]
+            if leaf:   # losses['sem'] with the leaf head on, one node (scripts/hierslam.py:963-983)
+                terms.append(L.semantic_loss_mlp(sem, lab_with_leaf, sizes, mlp, weight_sem=(0.1, 0.5)))
+            else:
+                terms.append(L.tree_cross_entropy(sem, lab, sizes, weights=[0.1] * len(sizes)))
             loss = L.weighted_sum(terms, weights, constant=0.5 * 0.2)
         else:
             ce, b = 0.0, 0
