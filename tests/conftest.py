@@ -27,6 +27,20 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True, scope="session")
+def _exact_semantic_alpha_mode_when_asked_for():
+    """HSR_TEST_SEM_ALPHA=exact: the library's opt-in exact semantic -> alpha mode for the whole session (the oracle follows: tests/oracle_lib.py)."""
+    if os.environ.get("HSR_TEST_SEM_ALPHA", "") == "exact":
+        try:
+            import torch
+            if torch.cuda.is_available():
+                from diff_gaussian_rasterization import _C
+                _C.set_semantic_alpha("exact")
+        except Exception:
+            pass
+    yield
+
+
 @pytest.fixture(autouse=True)
 def _cold_binning_hints_when_the_non_blocking_forward_is_forced(request):
     """HSR_ASYNC_FORWARD=1 runs the whole suite with the opt-in non-blocking forward.  That mode sizes the binning buffer from the last

@@ -97,7 +97,7 @@ def run_gpu(cam, sc, up, semantic=True, variant="sr", extra=None, dev="cuda:0", 
 
 
 def run_oracle(cam, sc, up, semantic=True, variant="sr", extra=None, threads=0, median_rule="forward", precision="f32", bounds=True,
-               sem_alpha_exact=False):
+               sem_alpha_exact=None):
     """median_rule: which splat receives dL_dmedian_depth in the oracle's backward — "forward" (default here): the one whose
     list position the forward recorded, as the HIP product does; "reference": the one the backward re-finds from its
     reconstructed T (backward.cu:623-626, :854-857).  They differ only on pixels whose T passes within rounding of 0.5;

@@ -169,9 +169,14 @@ def forward(cam, means3D, opacities, colors_precomp=None, shs=None, semantics_pr
     return out, st
 
 
+# HSR_TEST_SEM_ALPHA=exact: every oracle backward that does not say otherwise runs the exact semantic -> alpha mode, and tests/conftest.py
+# switches the library to it — the parity and fuzz tests then exercise the opt-in mode end to end (tools/r04_exact_fuzz.sh)
+DEFAULT_SEM_ALPHA_EXACT = os.environ.get("HSR_TEST_SEM_ALPHA", "") == "exact"
+
+
 def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_precomp=None, scales=None,
              rotations=None, cov3D_precomp=None, threads=0, median_rule="reference", bounds=False, fp32_atomics_seed=None, exp_ulps=0.0,
-             sem_alpha_exact=False, arg_roundings=0.0):
+             sem_alpha_exact=None, arg_roundings=0.0):
     """Oracle backward.  grads: dict(color[3,H,W], semantic[K,H,W]|None, depth, median, opacity).
     median_rule: "reference" = the splat the backward re-finds from its reconstructed T (backward.cu:623-626, :854-857);
     "forward" = the splat whose list position the forward recorded (what the HIP product does; identical except where the
@@ -180,6 +185,8 @@ def backward(st, cam, means3D, grads, colors_precomp=None, shs=None, semantics_p
     sem_alpha_exact: the semantic loss also reaches alpha (oracle sem_alpha_mode 1; the product's opt-in mode, default off = reference as observed).
     bounds=True: also the tie bounds of the gradients (oracle/hsr_oracle.c, "Threshold ties") as o["bounds"][name] — how far
     each gradient entry moves when the flagged threshold decisions of the flagged pixels are taken the other way."""
+    if sem_alpha_exact is None:
+        sem_alpha_exact = DEFAULT_SEM_ALPHA_EXACT
     L = lib(st.precision)
     rt = L.real
     # fp32_atomics_seed: the per-Gaussian sums are accumulated in fp32 in a seeded random tile order — one of the orders the reference's
