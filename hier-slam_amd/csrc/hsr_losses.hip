@@ -115,6 +115,89 @@ __global__ __launch_bounds__(LB) void l1_kernel(const float* __restrict__ pred, 
     if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
+// ---------------------------------------------------------------- tracking loss
+// The tracking branch of the reference's get_loss* (scripts/hierslam.py:903-937 with its shipped configs: use_l1, use_sil_for_loss,
+// no outlier rejection):  mask = (gt_depth > 0) & ~isnan(depth) & (silhouette > sil_thres);  depth term = sum |gt_depth - depth|[mask],
+// colour term = sum |gt_im - im|[mask tiled over the channels].  In torch that is six mask kernels, two boolean gathers, two abs / sum
+// chains and their autograd; here ONE pass forms both sums (the mask lives in a register) and ONE pass, run when autograd asks, writes
+// both gradients times the upstream gradient it reads from device memory.  Unselected pixels contribute nothing, whatever they hold.
+constexpr int TRK_ITEMS = 4;   // pixels per thread
+
+__device__ __forceinline__ bool tracking_selected(float gt_d, float d, float sil, float sil_thres, int use_sil)
+{
+    return gt_d > 0.f && !(d != d) && (!use_sil || sil > sil_thres);
+}
+
+__global__ __launch_bounds__(LB) void tracking_value_kernel(const float* __restrict__ im, const float* __restrict__ gt_im, int C,
+                                                            const float* __restrict__ depth, const float* __restrict__ gt_depth,
+                                                            const float* __restrict__ sil, float sil_thres, int use_sil, int N,
+                                                            float* __restrict__ partials /* [nblk][2]: depth sum, colour sum */)
+{
+    __shared__ float s_red[4];
+    float acc_d = 0.f, acc_c = 0.f;
+    for (int i = blockIdx.x * LB * TRK_ITEMS + threadIdx.x, it = 0; it < TRK_ITEMS; it++, i += LB) {
+        if (i >= N) break;
+        const float gd = gt_depth[i], d = depth[i];
+        const bool sel = tracking_selected(gd, d, use_sil ? sil[i] : 1.f, sil_thres, use_sil);
+        acc_d += sel ? fabsf(gd - d) : 0.f;
+        for (int c = 0; c < C; c++) {
+            const float e = fabsf(gt_im[(size_t)c * N + i] - im[(size_t)c * N + i]);
+            acc_c += sel ? e : 0.f;
+        }
+    }
+    const float td = block_sum(acc_d, s_red);
+    const float tc = block_sum(acc_c, s_red);
+    if (threadIdx.x == 0) {
+        partials[2 * (size_t)blockIdx.x] = td;
+        partials[2 * (size_t)blockIdx.x + 1] = tc;
+    }
+}
+
+// out[0] = depth sum, out[1] = colour sum, out[2] = w_depth * out[0] + w_im * out[1]   (fixed order, double)
+__global__ __launch_bounds__(1024) void tracking_finish_kernel(const float* __restrict__ partials, int nblocks, float w_depth, float w_im,
+                                                               float* __restrict__ out)
+{
+    __shared__ double s_acc[1024];
+    const int k = threadIdx.x & 1, j = threadIdx.x >> 1;   // 512 row groups x 2 columns
+    double acc = 0.0;
+    for (int b = j; b < nblocks; b += 512) acc += (double)partials[2 * (size_t)b + k];
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 512; o >= 2; o >>= 1) {
+        if ((int)threadIdx.x < o) s_acc[threadIdx.x] += s_acc[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)s_acc[0];
+        out[1] = (float)s_acc[1];
+        out[2] = (float)((double)w_depth * s_acc[0] + (double)w_im * s_acc[1]);
+    }
+}
+
+__global__ __launch_bounds__(LB) void tracking_grad_kernel(const float* __restrict__ im, const float* __restrict__ gt_im, int C,
+                                                           const float* __restrict__ depth, const float* __restrict__ gt_depth,
+                                                           const float* __restrict__ sil, float sil_thres, int use_sil, int N,
+                                                           const float* __restrict__ upstream, float w_depth, float w_im,
+                                                           float* __restrict__ d_im, float* __restrict__ d_depth)
+{
+    const float up = upstream ? upstream[0] : 1.0f;
+    const float sd = w_depth * up, sc = w_im * up;
+    for (int i = blockIdx.x * LB * TRK_ITEMS + threadIdx.x, it = 0; it < TRK_ITEMS; it++, i += LB) {
+        if (i >= N) break;
+        const float gd = gt_depth[i], d = depth[i];
+        const bool sel = tracking_selected(gd, d, use_sil ? sil[i] : 1.f, sil_thres, use_sil);
+        if (d_depth) {
+            const float e = d - gd;   // d |gt - d| / d d = sign(d - gt)
+            d_depth[i] = sel ? (e > 0.f ? sd : (e < 0.f ? -sd : 0.f)) : 0.f;
+        }
+        if (d_im)
+            for (int c = 0; c < C; c++) {
+                const float e = im[(size_t)c * N + i] - gt_im[(size_t)c * N + i];
+                d_im[(size_t)c * N + i] = sel ? (e > 0.f ? sc : (e < 0.f ? -sc : 0.f)) : 0.f;
+            }
+    }
+}
+
 // ---------------------------------------------------------------- SSIM
 // The reference's window is the outer product of a normalised 11-tap Gaussian with itself (utils/slam_external.py:60-62),
 // so the 121-tap correlation is evaluated as a horizontal then a vertical 11-tap pass (the two differ from the 2-D form by
@@ -764,6 +847,62 @@ extern "C" int hsr_loss_l1(int C, int H, int W, const float* pred, const float* 
     }
     l1_kernel<<<dim3(nb, C), LB, 0, stream>>>(pred, gt, mask, N, inv_arg, host_scale, out_grad, partials);
     finish_kernel<<<1, LB, 0, stream>>>(partials, C * nb, 1, 1, inv_arg, host_scale, out_loss);
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+namespace {
+int check_tracking(const char* who, int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
+                   const float* sil, int use_sil)
+{
+    if (C < 1 || H < 1 || W < 1 || (size_t)H * W > 0x7fffffffu || !im || !gt_im || !depth || !gt_depth || (use_sil && !sil)) {
+        hsr_set_error("%s: invalid sizes C=%d H=%d W=%d or NULL im / gt_im / depth / gt_depth / silhouette", who, C, H, W);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    return HSR_OK;
+}
+}  // namespace
+
+extern "C" size_t hsr_loss_tracking_scratch_bytes(int H, int W)
+{
+    if (H < 1 || W < 1) return 1024;
+    const size_t nb = ((size_t)H * W + LB * TRK_ITEMS - 1) / (LB * TRK_ITEMS);
+    return align256(nb * 2 * sizeof(float)) + 256;
+}
+
+extern "C" int hsr_loss_tracking_value(int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
+                                       const float* silhouette, float sil_thres, int use_sil, float w_depth, float w_im, float* out3,
+                                       char* scratch, size_t scratch_bytes, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_tracking("loss_tracking_value", C, H, W, im, gt_im, depth, gt_depth, silhouette, use_sil);
+    if (rc != HSR_OK) return rc;
+    if (!out3) {
+        hsr_set_error("loss_tracking_value: out3 is NULL");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    rc = check_scratch("loss_tracking_value", scratch, scratch_bytes, hsr_loss_tracking_scratch_bytes(H, W) - 256);
+    if (rc != HSR_OK) return rc;
+    const int N = H * W;
+    const int nb = (N + LB * TRK_ITEMS - 1) / (LB * TRK_ITEMS);
+    float* partials = reinterpret_cast<float*>(scratch);
+    tracking_value_kernel<<<nb, LB, 0, stream>>>(im, gt_im, C, depth, gt_depth, silhouette, sil_thres, use_sil, N, partials);
+    tracking_finish_kernel<<<1, 1024, 0, stream>>>(partials, nb, w_depth, w_im, out3);
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+extern "C" int hsr_loss_tracking_grad(int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
+                                      const float* silhouette, float sil_thres, int use_sil, float w_depth, float w_im, const float* upstream,
+                                      float* d_im, float* d_depth, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_tracking("loss_tracking_grad", C, H, W, im, gt_im, depth, gt_depth, silhouette, use_sil);
+    if (rc != HSR_OK) return rc;
+    const int N = H * W;
+    const int nb = (N + LB * TRK_ITEMS - 1) / (LB * TRK_ITEMS);
+    if (d_im || d_depth)
+        tracking_grad_kernel<<<nb, LB, 0, stream>>>(im, gt_im, C, depth, gt_depth, silhouette, sil_thres, use_sil, N, upstream, w_depth, w_im, d_im, d_depth);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
 }

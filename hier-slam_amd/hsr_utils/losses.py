@@ -35,6 +35,12 @@ _lib.hsr_loss_tree_ce_value.restype = _ci
 _lib.hsr_loss_tree_ce_value.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), _vp, _vp, _ci, _vp, _vp, _vp, _sz, _vp]
 _lib.hsr_loss_tree_ce_grad.restype = _ci
 _lib.hsr_loss_tree_ce_grad.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), C.POINTER(C.c_float), _vp, _vp, _ci, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp]
+_lib.hsr_loss_tracking_scratch_bytes.restype = _sz
+_lib.hsr_loss_tracking_scratch_bytes.argtypes = [_ci, _ci]
+_lib.hsr_loss_tracking_value.restype = _ci
+_lib.hsr_loss_tracking_value.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, C.c_float, _ci, C.c_float, C.c_float, _vp, _vp, _sz, _vp]
+_lib.hsr_loss_tracking_grad.restype = _ci
+_lib.hsr_loss_tracking_grad.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, C.c_float, _ci, C.c_float, C.c_float, _vp, _vp, _vp, _vp]
 _lib.hsr_loss_leaf_mlp_ce.restype = _ci
 _lib.hsr_loss_leaf_mlp_ce.argtypes = [_ci, _ci, _ci, _ci] + [_vp] * 4 + [_ci] + [_vp] * 5 + [_sz, _vp]
 
@@ -206,6 +212,71 @@ def weighted_sum(terms, weights, constant=0.0):
     if key not in _weight_cache:
         _weight_cache[key] = torch.tensor(w, dtype=torch.float32, device=dev)
     return _WeightedSum.apply(_weight_cache[key], *terms)
+
+
+class _TrackingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im, gt_im, depth, gt_depth, silhouette, sil_thres, use_sil, w_depth, w_im):
+        a, b = _chw(im, "im"), _chw(gt_im.detach(), "gt_im")
+        Cc, H, W = a.shape
+        d, gd = _chw(depth, "depth"), _chw(gt_depth.detach(), "gt_depth")
+        if b.shape != a.shape or d.numel() != H * W or gd.numel() != H * W:
+            raise RuntimeError("hsr_utils.losses: tracking_loss wants im / gt_im [C,H,W] and depth / gt_depth [1,H,W] of one size")
+        s = None
+        if use_sil:
+            s = _chw(silhouette.detach(), "silhouette")
+            if s.numel() != H * W:
+                raise RuntimeError("hsr_utils.losses: silhouette must be [1,H,W] like the depth map")
+        dev = a.device
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        sc = torch.empty(int(_lib.hsr_loss_tracking_scratch_bytes(H, W)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_tracking_value(Cc, H, W, a.data_ptr(), b.data_ptr(), d.data_ptr(), gd.data_ptr(), None if s is None else s.data_ptr(),
+                                              float(sil_thres), int(bool(use_sil)), float(w_depth), float(w_im), out.data_ptr(), sc.data_ptr(),
+                                              sc.numel(), _stream(dev))
+        if rc < 0:
+            _glue._fail(rc, "hsr_loss_tracking_value")
+        ctx.want = (bool(im.requires_grad), bool(depth.requires_grad))
+        if any(ctx.want):
+            ctx.save_for_backward(a, b, d, gd, s if s is not None else torch.empty(0, device=dev))
+            ctx.meta = (Cc, H, W, float(sil_thres), int(bool(use_sil)), float(w_depth), float(w_im), tuple(im.shape), tuple(depth.shape))
+        parts = out[:2].detach()
+        ctx.mark_non_differentiable(parts)
+        return out[2], parts
+
+    @staticmethod
+    def backward(ctx, g, _g_parts):
+        if g is None or not any(ctx.want):
+            return (None,) * 9
+        a, b, d, gd, s = ctx.saved_tensors
+        Cc, H, W, sil_thres, use_sil, w_depth, w_im, shape_im, shape_d = ctx.meta
+        dev = a.device
+        gg = g.to(device=dev, dtype=torch.float32).contiguous()
+        d_im = torch.empty_like(a) if ctx.want[0] else None
+        d_d = torch.empty_like(d) if ctx.want[1] else None
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_tracking_grad(Cc, H, W, a.data_ptr(), b.data_ptr(), d.data_ptr(), gd.data_ptr(), s.data_ptr() if use_sil else None,
+                                             sil_thres, use_sil, w_depth, w_im, gg.data_ptr(), None if d_im is None else d_im.data_ptr(),
+                                             None if d_d is None else d_d.data_ptr(), _stream(dev))
+        if rc < 0:
+            _glue._fail(rc, "hsr_loss_tracking_grad")
+        return (None if d_im is None else d_im.view(shape_im), None, None if d_d is None else d_d.view(shape_d), None, None, None, None, None, None)
+
+
+def tracking_loss(im, gt_im, depth, gt_depth, silhouette=None, sil_thres=0.99, use_sil_for_loss=True, loss_weights=None, return_parts=False):
+    """The tracking loss of the reference's get_loss* with its shipped tracking settings (scripts/hierslam.py:903-937, :1003-1016:
+    use_l1, ignore_outlier_depth_loss=False):
+        mask = (gt_depth > 0) & ~isnan(depth) & (silhouette > sil_thres)     [the last factor if use_sil_for_loss]
+        loss = loss_weights['depth'] * |gt_depth - depth|[mask].sum() + loss_weights['im'] * |gt_im - im|[tiled mask].sum()
+    as one autograd node: one pass for the value, one for both gradients.  loss_weights: dict with 'im' and 'depth' (default the
+    reference's tracking weights, im 0.5 / depth 1.0).  return_parts: also [depth sum, colour sum] (values, no gradient path).
+    The outlier-rejecting variant (a global median of the depth error) is not fused: compose masked_l1 with a torch mask for it."""
+    lw = loss_weights or {"im": 0.5, "depth": 1.0}
+    if use_sil_for_loss and silhouette is None:
+        raise RuntimeError("hsr_utils.losses: tracking_loss with use_sil_for_loss needs the rendered silhouette / final opacity map")
+    total, parts = _TrackingLoss.apply(im, gt_im, depth, gt_depth, silhouette, float(sil_thres), bool(use_sil_for_loss), float(lw["depth"]),
+                                       float(lw["im"]))
+    return (total, parts) if return_parts else total
 
 
 def l1_loss_v1(x, y):

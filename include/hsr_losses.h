@@ -40,6 +40,22 @@ size_t hsr_loss_scratch_bytes(int channels, int H, int W);
 int hsr_loss_l1(int C, int H, int W, const float* pred, const float* gt, const uint8_t* mask, int reduction, float* out_loss,
                 float* out_grad, char* scratch, size_t scratch_bytes, void* stream);
 
+/* The tracking loss of get_loss / get_loss_semantic / get_loss_semantic_mlp with the reference's shipped tracking settings (use_l1,
+ * ignore_outlier_depth_loss = False; scripts/hierslam.py:903-937, configs/replica/hierslam_semantic_run.py:75-84):
+ *     mask  = (gt_depth > 0) & ~isnan(depth) & (silhouette > sil_thres)          (the last factor only if use_sil)
+ *     depth = sum |gt_depth - depth|[mask]        im = sum |gt_im - im|[mask tiled over the C channels]
+ * Value pass: out3 (DEVICE float[3]) = { depth, im, w_depth * depth + w_im * im }.  Gradient pass (when autograd asks):
+ * d_im ([C,H,W]) / d_depth ([H,W]) = upstream[0] * w * sign(pred - gt) on the selected pixels, 0 elsewhere (`upstream`: DEVICE
+ * float, NULL = 1; either output may be NULL).  The silhouette enters the mask only (the reference detaches it there).
+ * im / gt_im: [C,H,W]; depth / gt_depth / silhouette: [H,W].  Scratch: hsr_loss_tracking_scratch_bytes(H, W). */
+size_t hsr_loss_tracking_scratch_bytes(int H, int W);
+int hsr_loss_tracking_value(int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
+                            const float* silhouette, float sil_thres, int use_sil, float w_depth, float w_im, float* out3, char* scratch,
+                            size_t scratch_bytes, void* stream);
+int hsr_loss_tracking_grad(int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
+                           const float* silhouette, float sil_thres, int use_sil, float w_depth, float w_im, const float* upstream,
+                           float* d_im, float* d_depth, void* stream);
+
 /* calc_ssim(img1, img2, window_size = 11, size_average = True) (utils/slam_external.py:66-97).  out_ssim: float[1];
  * out_grad ([C,H,W], may be NULL) receives d ssim / d img1. */
 int hsr_loss_ssim(int C, int H, int W, const float* img1, const float* img2, float* out_ssim, float* out_grad, char* scratch,

@@ -346,3 +346,49 @@ def test_semantic_loss_mlp_is_the_two_heads_it_fuses():
     assert abs(float(0.1 * levels.sum() + 0.5 * leaf) - float(got)) <= 2e-6 * abs(float(got))
     for name, x, y in (("d sem", b.grad, want[0]), ("d weight", mlp.weight.grad, want[1]), ("d bias", mlp.bias.grad, want[2])):
         assert _relmax(x.cpu().numpy(), y.cpu().numpy()) < 2e-6, name
+
+
+@pytest.mark.parametrize("use_sil", [True, False])
+def test_tracking_loss_is_the_reference_tracking_branch(use_sil):
+    """L.tracking_loss against the torch expressions of scripts/hierslam.py:903-937 (mask from gt depth > 0, ~isnan(depth), silhouette >
+    sil_thres; masked |.| sums; weights im 0.5 / depth 1.0), on a ragged size, with NaNs outside the mask, invalid gt depth, and an
+    upstream gradient != 1."""
+    from hsr_utils import losses as L
+    g = torch.Generator().manual_seed(5)
+    H, W = 61, 93
+    im, gt_im = torch.rand(3, H, W, generator=g).cuda(), torch.rand(3, H, W, generator=g).cuda()
+    depth, gt_d = (torch.rand(1, H, W, generator=g) * 5).cuda(), (torch.rand(1, H, W, generator=g) * 5).cuda()
+    sil = torch.rand(1, H, W, generator=g).cuda()
+    gt_d[0, :7] = 0.0
+    depth[0, 10, 5:20] = float("nan")
+    im[:, 30, 40] = gt_im[:, 30, 40]              # exact zeros of the error: gradient 0 there, as torch's sign(0)
+    a, d = im.clone().requires_grad_(True), depth.clone().requires_grad_(True)
+    mask = (gt_d > 0) & ~torch.isnan(d)
+    if use_sil:
+        mask = mask & (sil > 0.6)
+    mask = mask.detach()
+    ref_d = torch.abs(gt_d - d)[mask].sum()
+    ref_c = torch.abs(gt_im - a)[torch.tile(mask, (3, 1, 1))].sum()
+    ref = 1.0 * ref_d + 0.5 * ref_c
+    (1.7 * ref).backward()
+    want = (a.grad.clone(), d.grad.clone())
+    a2, d2 = im.clone().requires_grad_(True), depth.clone().requires_grad_(True)
+    got, parts = L.tracking_loss(a2, gt_im, d2, gt_d, sil if use_sil else None, sil_thres=0.6, use_sil_for_loss=use_sil, return_parts=True)
+    (1.7 * got).backward()
+    torch.cuda.synchronize()
+    assert abs(float(got) - float(ref)) <= VAL_TOL * abs(float(ref))
+    assert abs(float(parts[0]) - float(ref_d)) <= VAL_TOL * abs(float(ref_d)) and abs(float(parts[1]) - float(ref_c)) <= VAL_TOL * abs(float(ref_c))
+    assert torch.equal(a2.grad, want[0]) and torch.equal(torch.nan_to_num(d2.grad), torch.nan_to_num(want[1]))
+    assert not torch.isnan(d2.grad).any()          # unselected pixels get 0 whatever they hold
+
+
+def test_tracking_loss_rejects_bad_input():
+    from hsr_utils import losses as L
+    z = torch.zeros(3, 8, 8, device="cuda")
+    d = torch.zeros(1, 8, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="silhouette"):
+        L.tracking_loss(z, z, d, d, None)
+    with pytest.raises(RuntimeError, match="one size"):
+        L.tracking_loss(z, z, torch.zeros(1, 8, 9, device="cuda"), d, d)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        L.tracking_loss(z.cpu(), z, d, d, d)

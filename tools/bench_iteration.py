@@ -119,12 +119,13 @@ def measure(P=500000, W=1200, H=680, iters=20):
         if pose_only:
             rv = {k: (v if k in ("means3D", "means2D") or v is None else v.detach()) for k, v in rv.items()}
         im, radius, sem, depth, med, opac = GaussianRasterizer_semantic(raster_settings=cam)(**rv)
-        mask = ((gt_d > 0) & ~torch.isnan(depth) & (opac > 0.99)).detach()
-        if fused and os.environ.get("HSR_ITER_PLAIN_SUM"):
+        if fused and os.environ.get("HSR_ITER_PLAIN_SUM"):   # round 3's composition: torch mask + two masked L1 heads + Python arithmetic
+            mask = ((gt_d > 0) & ~torch.isnan(depth) & (opac > 0.99)).detach()
             loss = L.masked_l1(depth, gt_d, mask, "sum") + 0.5 * L.masked_l1(im, gt_im, mask, "sum")
-        elif fused:
-            loss = L.weighted_sum((L.masked_l1(depth, gt_d, mask, "sum"), L.masked_l1(im, gt_im, mask, "sum")), (1.0, 0.5))
+        elif fused:   # the tracking branch of get_loss* as one node (mask, both sums, the weights)
+            loss = L.tracking_loss(im, gt_im, depth, gt_d, opac, sil_thres=0.99, loss_weights={"im": 0.5, "depth": 1.0})
         else:
+            mask = ((gt_d > 0) & ~torch.isnan(depth) & (opac > 0.99)).detach()
             loss = torch.abs(gt_d - depth)[mask].sum() + 0.5 * torch.abs(gt_im - im)[torch.tile(mask, (3, 1, 1))].sum()
         loss.backward()
         return loss
