@@ -131,15 +131,16 @@ __device__ __forceinline__ bool tracking_selected(float gt_d, float d, float sil
 __global__ __launch_bounds__(LB) void tracking_value_kernel(const float* __restrict__ im, const float* __restrict__ gt_im, int C,
                                                             const float* __restrict__ depth, const float* __restrict__ gt_depth,
                                                             const float* __restrict__ sil, float sil_thres, int use_sil, int N,
-                                                            float* __restrict__ partials /* [nblk][2]: depth sum, colour sum */)
+                                                            float* __restrict__ partials /* [nblk][3]: depth sum, colour sum, selected pixels */)
 {
     __shared__ float s_red[4];
-    float acc_d = 0.f, acc_c = 0.f;
+    float acc_d = 0.f, acc_c = 0.f, acc_n = 0.f;
     for (int i = blockIdx.x * LB * TRK_ITEMS + threadIdx.x, it = 0; it < TRK_ITEMS; it++, i += LB) {
         if (i >= N) break;
         const float gd = gt_depth[i], d = depth[i];
         const bool sel = tracking_selected(gd, d, use_sil ? sil[i] : 1.f, sil_thres, use_sil);
         acc_d += sel ? fabsf(gd - d) : 0.f;
+        acc_n += sel ? 1.f : 0.f;   // exact in fp32: at most LB * TRK_ITEMS per block
         for (int c = 0; c < C; c++) {
             const float e = fabsf(gt_im[(size_t)c * N + i] - im[(size_t)c * N + i]);
             acc_c += sel ? e : 0.f;
@@ -147,30 +148,39 @@ __global__ __launch_bounds__(LB) void tracking_value_kernel(const float* __restr
     }
     const float td = block_sum(acc_d, s_red);
     const float tc = block_sum(acc_c, s_red);
+    const float tn = block_sum(acc_n, s_red);
     if (threadIdx.x == 0) {
-        partials[2 * (size_t)blockIdx.x] = td;
-        partials[2 * (size_t)blockIdx.x + 1] = tc;
+        partials[3 * (size_t)blockIdx.x] = td;
+        partials[3 * (size_t)blockIdx.x + 1] = tc;
+        partials[3 * (size_t)blockIdx.x + 2] = tn;
     }
 }
 
-// out[0] = depth sum, out[1] = colour sum, out[2] = w_depth * out[0] + w_im * out[1]   (fixed order, double)
+// out[0] = depth term, out[1] = colour term, out[2] = w_depth * out[0] + w_im * out[1], out[3] = 1 / selected pixels (fixed order, double).
+// mean: the terms are means over the selection (colour: over the selection tiled over its C planes) — an empty selection gives NaN like torch.
 __global__ __launch_bounds__(1024) void tracking_finish_kernel(const float* __restrict__ partials, int nblocks, float w_depth, float w_im,
-                                                               float* __restrict__ out)
+                                                               int mean, int C, float* __restrict__ out)
 {
-    __shared__ double s_acc[1024];
-    const int k = threadIdx.x & 1, j = threadIdx.x >> 1;   // 512 row groups x 2 columns
+    __shared__ double s_acc[256][4];
+    const int k = threadIdx.x & 3, j = threadIdx.x >> 2;   // 256 row groups x (3 columns + 1 idle)
     double acc = 0.0;
-    for (int b = j; b < nblocks; b += 512) acc += (double)partials[2 * (size_t)b + k];
-    s_acc[threadIdx.x] = acc;
+    if (k < 3)
+        for (int b = j; b < nblocks; b += 256) acc += (double)partials[3 * (size_t)b + k];
+    s_acc[j][k] = acc;
     __syncthreads();
-    for (int o = 512; o >= 2; o >>= 1) {
-        if ((int)threadIdx.x < o) s_acc[threadIdx.x] += s_acc[threadIdx.x + o];
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (j < o) s_acc[j][k] += s_acc[j + o][k];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out[0] = (float)s_acc[0];
-        out[1] = (float)s_acc[1];
-        out[2] = (float)((double)w_depth * s_acc[0] + (double)w_im * s_acc[1]);
+        const double n = s_acc[0][2];
+        const float inv = 1.0f / (float)n;
+        const double dterm = mean ? s_acc[0][0] * (double)inv : s_acc[0][0];
+        const double cterm = mean ? (C > 0 ? s_acc[0][1] * (double)inv / (double)C : 0.0) : s_acc[0][1];
+        out[0] = (float)dterm;
+        out[1] = (float)cterm;
+        out[2] = (float)((double)w_depth * dterm + (double)w_im * cterm);
+        out[3] = inv;
     }
 }
 
@@ -178,10 +188,11 @@ __global__ __launch_bounds__(LB) void tracking_grad_kernel(const float* __restri
                                                            const float* __restrict__ depth, const float* __restrict__ gt_depth,
                                                            const float* __restrict__ sil, float sil_thres, int use_sil, int N,
                                                            const float* __restrict__ upstream, float w_depth, float w_im,
-                                                           float* __restrict__ d_im, float* __restrict__ d_depth)
+                                                           const float* __restrict__ inv_count, float* __restrict__ d_im, float* __restrict__ d_depth)
 {
     const float up = upstream ? upstream[0] : 1.0f;
-    const float sd = w_depth * up, sc = w_im * up;
+    const float inv = inv_count ? inv_count[0] : 1.0f;   // mean reduction: 1 / selected pixels (the value pass's out[3])
+    const float sd = w_depth * up * inv, sc = w_im * up * (inv_count ? inv / (float)(C > 0 ? C : 1) : 1.0f);
     for (int i = blockIdx.x * LB * TRK_ITEMS + threadIdx.x, it = 0; it < TRK_ITEMS; it++, i += LB) {
         if (i >= N) break;
         const float gd = gt_depth[i], d = depth[i];
@@ -855,7 +866,7 @@ namespace {
 int check_tracking(const char* who, int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
                    const float* sil, int use_sil)
 {
-    if (C < 1 || H < 1 || W < 1 || (size_t)H * W > 0x7fffffffu || !im || !gt_im || !depth || !gt_depth || (use_sil && !sil)) {
+    if (C < 0 || H < 1 || W < 1 || (size_t)H * W > 0x7fffffffu || (C > 0 && (!im || !gt_im)) || !depth || !gt_depth || (use_sil && !sil)) {
         hsr_set_error("%s: invalid sizes C=%d H=%d W=%d or NULL im / gt_im / depth / gt_depth / silhouette", who, C, H, W);
         return HSR_ERR_INVALID_ARGUMENT;
     }
@@ -867,18 +878,18 @@ extern "C" size_t hsr_loss_tracking_scratch_bytes(int H, int W)
 {
     if (H < 1 || W < 1) return 1024;
     const size_t nb = ((size_t)H * W + LB * TRK_ITEMS - 1) / (LB * TRK_ITEMS);
-    return align256(nb * 2 * sizeof(float)) + 256;
+    return align256(nb * 3 * sizeof(float)) + 256;
 }
 
 extern "C" int hsr_loss_tracking_value(int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
-                                       const float* silhouette, float sil_thres, int use_sil, float w_depth, float w_im, float* out3,
-                                       char* scratch, size_t scratch_bytes, void* stream_)
+                                       const float* silhouette, float sil_thres, int use_sil, int reduction, float w_depth, float w_im,
+                                       float* out4, char* scratch, size_t scratch_bytes, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     int rc = check_tracking("loss_tracking_value", C, H, W, im, gt_im, depth, gt_depth, silhouette, use_sil);
     if (rc != HSR_OK) return rc;
-    if (!out3) {
-        hsr_set_error("loss_tracking_value: out3 is NULL");
+    if (!out4 || (reduction != HSR_LOSS_SUM && reduction != HSR_LOSS_MEAN)) {
+        hsr_set_error("loss_tracking_value: out4 is NULL or reduction is neither HSR_LOSS_SUM nor HSR_LOSS_MEAN");
         return HSR_ERR_INVALID_ARGUMENT;
     }
     rc = check_scratch("loss_tracking_value", scratch, scratch_bytes, hsr_loss_tracking_scratch_bytes(H, W) - 256);
@@ -887,14 +898,14 @@ extern "C" int hsr_loss_tracking_value(int C, int H, int W, const float* im, con
     const int nb = (N + LB * TRK_ITEMS - 1) / (LB * TRK_ITEMS);
     float* partials = reinterpret_cast<float*>(scratch);
     tracking_value_kernel<<<nb, LB, 0, stream>>>(im, gt_im, C, depth, gt_depth, silhouette, sil_thres, use_sil, N, partials);
-    tracking_finish_kernel<<<1, 1024, 0, stream>>>(partials, nb, w_depth, w_im, out3);
+    tracking_finish_kernel<<<1, 1024, 0, stream>>>(partials, nb, w_depth, w_im, reduction == HSR_LOSS_MEAN ? 1 : 0, C, out4);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
 }
 
 extern "C" int hsr_loss_tracking_grad(int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
                                       const float* silhouette, float sil_thres, int use_sil, float w_depth, float w_im, const float* upstream,
-                                      float* d_im, float* d_depth, void* stream_)
+                                      const float* inv_count, float* d_im, float* d_depth, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     int rc = check_tracking("loss_tracking_grad", C, H, W, im, gt_im, depth, gt_depth, silhouette, use_sil);
@@ -902,7 +913,8 @@ extern "C" int hsr_loss_tracking_grad(int C, int H, int W, const float* im, cons
     const int N = H * W;
     const int nb = (N + LB * TRK_ITEMS - 1) / (LB * TRK_ITEMS);
     if (d_im || d_depth)
-        tracking_grad_kernel<<<nb, LB, 0, stream>>>(im, gt_im, C, depth, gt_depth, silhouette, sil_thres, use_sil, N, upstream, w_depth, w_im, d_im, d_depth);
+        tracking_grad_kernel<<<nb, LB, 0, stream>>>(im, gt_im, C, depth, gt_depth, silhouette, sil_thres, use_sil, N, upstream, w_depth, w_im, inv_count,
+                                                    C > 0 ? d_im : nullptr, d_depth);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
 }

@@ -38,9 +38,9 @@ _lib.hsr_loss_tree_ce_grad.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), C.POI
 _lib.hsr_loss_tracking_scratch_bytes.restype = _sz
 _lib.hsr_loss_tracking_scratch_bytes.argtypes = [_ci, _ci]
 _lib.hsr_loss_tracking_value.restype = _ci
-_lib.hsr_loss_tracking_value.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, C.c_float, _ci, C.c_float, C.c_float, _vp, _vp, _sz, _vp]
+_lib.hsr_loss_tracking_value.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, C.c_float, _ci, _ci, C.c_float, C.c_float, _vp, _vp, _sz, _vp]
 _lib.hsr_loss_tracking_grad.restype = _ci
-_lib.hsr_loss_tracking_grad.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, C.c_float, _ci, C.c_float, C.c_float, _vp, _vp, _vp, _vp]
+_lib.hsr_loss_tracking_grad.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, C.c_float, _ci, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]
 _lib.hsr_loss_leaf_mlp_ce.restype = _ci
 _lib.hsr_loss_leaf_mlp_ce.argtypes = [_ci, _ci, _ci, _ci] + [_vp] * 4 + [_ci] + [_vp] * 5 + [_sz, _vp]
 
@@ -216,30 +216,36 @@ def weighted_sum(terms, weights, constant=0.0):
 
 class _TrackingLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, im, gt_im, depth, gt_depth, silhouette, sil_thres, use_sil, w_depth, w_im):
-        a, b = _chw(im, "im"), _chw(gt_im.detach(), "gt_im")
-        Cc, H, W = a.shape
+    def forward(ctx, im, gt_im, depth, gt_depth, silhouette, sil_thres, use_sil, w_depth, w_im, reduction):
         d, gd = _chw(depth, "depth"), _chw(gt_depth.detach(), "gt_depth")
-        if b.shape != a.shape or d.numel() != H * W or gd.numel() != H * W:
+        if im is None:      # depth term alone (the mapping branch)
+            a = b = None
+            Cc, (H, W) = 0, d.shape[-2:]
+        else:
+            a, b = _chw(im, "im"), _chw(gt_im.detach(), "gt_im")
+            Cc, H, W = a.shape
+        if (a is not None and b.shape != a.shape) or d.numel() != H * W or gd.numel() != H * W:
             raise RuntimeError("hsr_utils.losses: tracking_loss wants im / gt_im [C,H,W] and depth / gt_depth [1,H,W] of one size")
         s = None
         if use_sil:
             s = _chw(silhouette.detach(), "silhouette")
             if s.numel() != H * W:
                 raise RuntimeError("hsr_utils.losses: silhouette must be [1,H,W] like the depth map")
-        dev = a.device
-        out = torch.empty(3, dtype=torch.float32, device=dev)
+        dev = d.device
+        out = torch.empty(4, dtype=torch.float32, device=dev)
         sc = torch.empty(int(_lib.hsr_loss_tracking_scratch_bytes(H, W)), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            rc = _lib.hsr_loss_tracking_value(Cc, H, W, a.data_ptr(), b.data_ptr(), d.data_ptr(), gd.data_ptr(), None if s is None else s.data_ptr(),
-                                              float(sil_thres), int(bool(use_sil)), float(w_depth), float(w_im), out.data_ptr(), sc.data_ptr(),
-                                              sc.numel(), _stream(dev))
+            rc = _lib.hsr_loss_tracking_value(Cc, H, W, None if a is None else a.data_ptr(), None if b is None else b.data_ptr(), d.data_ptr(),
+                                              gd.data_ptr(), None if s is None else s.data_ptr(), float(sil_thres), int(bool(use_sil)), int(reduction),
+                                              float(w_depth), float(w_im), out.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev))
         if rc < 0:
             _glue._fail(rc, "hsr_loss_tracking_value")
-        ctx.want = (bool(im.requires_grad), bool(depth.requires_grad))
+        ctx.want = (bool(im is not None and im.requires_grad), bool(depth.requires_grad))
         if any(ctx.want):
-            ctx.save_for_backward(a, b, d, gd, s if s is not None else torch.empty(0, device=dev))
-            ctx.meta = (Cc, H, W, float(sil_thres), int(bool(use_sil)), float(w_depth), float(w_im), tuple(im.shape), tuple(depth.shape))
+            e = torch.empty(0, device=dev)
+            ctx.save_for_backward(a if a is not None else e, b if b is not None else e, d, gd, s if s is not None else e, out)
+            ctx.meta = (Cc, H, W, float(sil_thres), int(bool(use_sil)), float(w_depth), float(w_im), None if im is None else tuple(im.shape),
+                        tuple(depth.shape), int(reduction))
         parts = out[:2].detach()
         ctx.mark_non_differentiable(parts)
         return out[2], parts
@@ -247,20 +253,21 @@ class _TrackingLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g_parts):
         if g is None or not any(ctx.want):
-            return (None,) * 9
-        a, b, d, gd, s = ctx.saved_tensors
-        Cc, H, W, sil_thres, use_sil, w_depth, w_im, shape_im, shape_d = ctx.meta
-        dev = a.device
+            return (None,) * 10
+        a, b, d, gd, s, out = ctx.saved_tensors
+        Cc, H, W, sil_thres, use_sil, w_depth, w_im, shape_im, shape_d, reduction = ctx.meta
+        dev = d.device
         gg = g.to(device=dev, dtype=torch.float32).contiguous()
         d_im = torch.empty_like(a) if ctx.want[0] else None
         d_d = torch.empty_like(d) if ctx.want[1] else None
+        inv_ptr = out.data_ptr() + 12 if reduction == MEAN else None     # &out4[3]: 1 / selected pixels
         with torch.cuda.device(dev):
-            rc = _lib.hsr_loss_tracking_grad(Cc, H, W, a.data_ptr(), b.data_ptr(), d.data_ptr(), gd.data_ptr(), s.data_ptr() if use_sil else None,
-                                             sil_thres, use_sil, w_depth, w_im, gg.data_ptr(), None if d_im is None else d_im.data_ptr(),
-                                             None if d_d is None else d_d.data_ptr(), _stream(dev))
+            rc = _lib.hsr_loss_tracking_grad(Cc, H, W, a.data_ptr() if Cc else None, b.data_ptr() if Cc else None, d.data_ptr(), gd.data_ptr(),
+                                             s.data_ptr() if use_sil else None, sil_thres, use_sil, w_depth, w_im, gg.data_ptr(), inv_ptr,
+                                             None if d_im is None else d_im.data_ptr(), None if d_d is None else d_d.data_ptr(), _stream(dev))
         if rc < 0:
             _glue._fail(rc, "hsr_loss_tracking_grad")
-        return (None if d_im is None else d_im.view(shape_im), None, None if d_d is None else d_d.view(shape_d), None, None, None, None, None, None)
+        return (None if d_im is None else d_im.view(shape_im), None, None if d_d is None else d_d.view(shape_d), None, None, None, None, None, None, None)
 
 
 def tracking_loss(im, gt_im, depth, gt_depth, silhouette=None, sil_thres=0.99, use_sil_for_loss=True, loss_weights=None, return_parts=False):
@@ -275,8 +282,16 @@ def tracking_loss(im, gt_im, depth, gt_depth, silhouette=None, sil_thres=0.99, u
     if use_sil_for_loss and silhouette is None:
         raise RuntimeError("hsr_utils.losses: tracking_loss with use_sil_for_loss needs the rendered silhouette / final opacity map")
     total, parts = _TrackingLoss.apply(im, gt_im, depth, gt_depth, silhouette, float(sil_thres), bool(use_sil_for_loss), float(lw["depth"]),
-                                       float(lw["im"]))
+                                       float(lw["im"]), SUM)
     return (total, parts) if return_parts else total
+
+
+def mapping_depth_loss(depth, gt_depth):
+    """The depth term of the mapping branch of get_loss* (scripts/hierslam.py:905-927 with the shipped mapping settings: no silhouette
+    mask, no outlier rejection):  torch.abs(gt_depth - depth)[(gt_depth > 0) & ~isnan(depth)].mean()  — mask, count and mean in one pass,
+    the gradient in a second when autograd asks (no mask tensor, no count pre-pass)."""
+    total, _parts = _TrackingLoss.apply(None, None, depth, gt_depth, None, 0.0, False, 1.0, 0.0, MEAN)
+    return total
 
 
 def l1_loss_v1(x, y):

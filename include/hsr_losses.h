@@ -44,17 +44,20 @@ int hsr_loss_l1(int C, int H, int W, const float* pred, const float* gt, const u
  * ignore_outlier_depth_loss = False; scripts/hierslam.py:903-937, configs/replica/hierslam_semantic_run.py:75-84):
  *     mask  = (gt_depth > 0) & ~isnan(depth) & (silhouette > sil_thres)          (the last factor only if use_sil)
  *     depth = sum |gt_depth - depth|[mask]        im = sum |gt_im - im|[mask tiled over the C channels]
- * Value pass: out3 (DEVICE float[3]) = { depth, im, w_depth * depth + w_im * im }.  Gradient pass (when autograd asks):
- * d_im ([C,H,W]) / d_depth ([H,W]) = upstream[0] * w * sign(pred - gt) on the selected pixels, 0 elsewhere (`upstream`: DEVICE
+ * Value pass: out4 (DEVICE float[4]) = { depth, im, w_depth * depth + w_im * im, 1 / selected pixels }.  Gradient pass (when autograd
+ * asks): d_im ([C,H,W]) / d_depth ([H,W]) = upstream[0] * w * sign(pred - gt) on the selected pixels, 0 elsewhere (`upstream`: DEVICE
  * float, NULL = 1; either output may be NULL).  The silhouette enters the mask only (the reference detaches it there).
+ * reduction HSR_LOSS_MEAN: the mapping branch's depth term, torch.abs(gt_depth - depth)[mask].mean() with mask = (gt_depth > 0) &
+ * ~isnan(depth) (scripts/hierslam.py:927; use_sil = 0 there, C = 0 skips the colour term: im / gt_im / d_im NULL) — the gradient pass
+ * then takes `inv_count` = &out4[3] of the value pass (NULL for sums).
  * im / gt_im: [C,H,W]; depth / gt_depth / silhouette: [H,W].  Scratch: hsr_loss_tracking_scratch_bytes(H, W). */
 size_t hsr_loss_tracking_scratch_bytes(int H, int W);
 int hsr_loss_tracking_value(int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
-                            const float* silhouette, float sil_thres, int use_sil, float w_depth, float w_im, float* out3, char* scratch,
-                            size_t scratch_bytes, void* stream);
+                            const float* silhouette, float sil_thres, int use_sil, int reduction, float w_depth, float w_im, float* out4,
+                            char* scratch, size_t scratch_bytes, void* stream);
 int hsr_loss_tracking_grad(int C, int H, int W, const float* im, const float* gt_im, const float* depth, const float* gt_depth,
                            const float* silhouette, float sil_thres, int use_sil, float w_depth, float w_im, const float* upstream,
-                           float* d_im, float* d_depth, void* stream);
+                           const float* inv_count, float* d_im, float* d_depth, void* stream);
 
 /* calc_ssim(img1, img2, window_size = 11, size_average = True) (utils/slam_external.py:66-97).  out_ssim: float[1];
  * out_grad ([C,H,W], may be NULL) receives d ssim / d img1. */

@@ -392,3 +392,26 @@ def test_tracking_loss_rejects_bad_input():
         L.tracking_loss(z, z, torch.zeros(1, 8, 9, device="cuda"), d, d)
     with pytest.raises(RuntimeError, match="HIP device"):
         L.tracking_loss(z.cpu(), z, d, d, d)
+
+
+def test_mapping_depth_loss_is_the_reference_mapping_branch():
+    """L.mapping_depth_loss against torch.abs(gt - depth)[(gt > 0) & ~isnan(depth)].mean() (scripts/hierslam.py:905-927), value and gradient with
+    an upstream gradient != 1; an empty selection gives NaN like torch."""
+    from hsr_utils import losses as L
+    g = torch.Generator().manual_seed(8)
+    H, W = 57, 131
+    depth, gt_d = (torch.rand(1, H, W, generator=g) * 5).cuda(), (torch.rand(1, H, W, generator=g) * 5).cuda()
+    gt_d[0, :9] = 0.0
+    depth[0, 20, 3:30] = float("nan")
+    d = depth.clone().requires_grad_(True)
+    mask = ((gt_d > 0) & ~torch.isnan(d)).detach()
+    ref = torch.abs(gt_d - d)[mask].mean()
+    (0.3 * ref).backward()
+    want = d.grad.clone()
+    d2 = depth.clone().requires_grad_(True)
+    got = L.mapping_depth_loss(d2, gt_d)
+    (0.3 * got).backward()
+    torch.cuda.synchronize()
+    assert abs(float(got) - float(ref)) <= VAL_TOL * abs(float(ref))
+    assert _relmax(torch.nan_to_num(d2.grad).cpu().numpy(), torch.nan_to_num(want).cpu().numpy()) < GRAD_TOL and not torch.isnan(d2.grad).any()
+    assert torch.isnan(L.mapping_depth_loss(depth, torch.zeros_like(gt_d)))

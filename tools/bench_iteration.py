@@ -72,10 +72,11 @@ def measure(P=500000, W=1200, H=680, iters=20):
         rv = SH.transformed_params2rendervar_semantic(params, SH.transform_to_frame(params, 1, True, False)) if fused else eager_prep(params, 1)
         rv['means2D'].retain_grad()
         im, radius, sem, depth, med, opac = GaussianRasterizer_semantic(raster_settings=cam)(**rv)
-        mask = ((gt_d > 0) & ~torch.isnan(depth)).detach()
+        if not fused:
+            mask = ((gt_d > 0) & ~torch.isnan(depth)).detach()
         if fused:
             # the weighted dictionary sum of scripts/hierslam.py:1003-1016 as one node (L.weighted_sum) instead of Python arithmetic on 0-dim tensors
-            terms = [L.l1_loss_v1(im, gt_im), L.calc_ssim(im, gt_im), L.masked_l1(depth, gt_d, mask, "mean")]
+            terms = [L.l1_loss_v1(im, gt_im), L.calc_ssim(im, gt_im), L.mapping_depth_loss(depth, gt_d)]
             weights = [0.5 * 0.8, -0.5 * 0.2, 1.0, 1.0]
             if leaf:   # losses['sem'] with the leaf head on, one node (scripts/hierslam.py:963-983)
                 terms.append(L.semantic_loss_mlp(sem, lab_with_leaf, sizes, mlp, weight_sem=(0.1, 0.5)))
