@@ -427,8 +427,11 @@ __global__ __launch_bounds__(LB) void tree_ce_kernel(const float* __restrict__ l
 // A level of at most CE_REG channels is held in registers: all its loads go out together, one expf per channel, no second read.
 constexpr int CE_REG = 16;
 
-template <bool GRAD>
-__global__ __launch_bounds__(LB) void tree_ce2_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int N, int K,
+constexpr int CE_ITEMS = 1;   // pixels per thread (2 was measured: 41 + 47 us against 37 + 41 — fewer independent loads in flight per lane than two threads give)
+
+// TB: threads per block — the value pass runs 1 024 (a quarter of the block partials for its one-block finisher), the gradient pass 256
+template <bool GRAD, int TB>
+__global__ __launch_bounds__(TB) void tree_ce2_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int N, int K,
                                                       Levels lv, int ignore_index, const float* __restrict__ inv_count,
                                                       const float* __restrict__ upstream, float* __restrict__ grad,
                                                       float* __restrict__ partials /* [nblk][2 * MAX_LEVELS]: loss sums, then counts */,
@@ -437,101 +440,101 @@ __global__ __launch_bounds__(LB) void tree_ce2_kernel(const float* __restrict__ 
     // GRAD: out = tree part + add_grad * (add_scale[0] * add_host_scale) — another head's stashed gradient of the same map (the leaf head's)
     // joins here instead of costing its own `stash * g` pass and autograd's add of the two K x H x W maps
     const float as = (GRAD && add_grad) ? (add_scale ? add_scale[0] : 1.0f) * add_host_scale : 0.f;
-    __shared__ float s_part[4][2 * HSR_LOSS_MAX_LEVELS];
-    const int i = blockIdx.x * LB + threadIdx.x;
-    const bool live = i < N;
-    const size_t p = live ? (size_t)i : 0;
+    __shared__ float s_part[TB / 64][2 * HSR_LOSS_MAX_LEVELS];   // per wave: loss sums, counts (each wave adds into its own row: no atomics)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (!GRAD && lane < 2 * HSR_LOSS_MAX_LEVELS) s_part[wv][lane] = 0.f;
     const float up = GRAD ? (upstream ? upstream[0] : 1.0f) : 0.f;
-    float lsum[HSR_LOSS_MAX_LEVELS], lcnt[HSR_LOSS_MAX_LEVELS];
-    int covered_end = 0;
 #pragma unroll 1
-    for (int l = 0; l < lv.n; l++) {
-        const int b = lv.begin[l], n = lv.size[l];
-        const int64_t lab64 = labels[(size_t)l * N + p];
-        const bool valid = live && lab64 != (int64_t)ignore_index;
-        const int lab = (int)lab64;
-        const float sc = GRAD ? (valid ? lv.weight[l] * inv_count[l] * up : 0.f) : 0.f;
-        float loss = 0.f;
-        if (n <= CE_REG) {
-            float z[CE_REG];
+    for (int it = 0; it < CE_ITEMS; it++) {
+        const int i = (blockIdx.x * CE_ITEMS + it) * TB + (int)threadIdx.x;
+        const bool live = i < N;
+        const size_t p = live ? (size_t)i : 0;
+        int covered_end = 0;
+#pragma unroll 1
+        for (int l = 0; l < lv.n; l++) {
+            const int b = lv.begin[l], n = lv.size[l];
+            const int64_t lab64 = labels[(size_t)l * N + p];
+            const bool valid = live && lab64 != (int64_t)ignore_index;
+            const int lab = (int)lab64;
+            const float sc = GRAD ? (valid ? lv.weight[l] * inv_count[l] * up : 0.f) : 0.f;
+            float loss = 0.f;
+            if (n <= CE_REG) {
+                float z[CE_REG];
 #pragma unroll
-            for (int c = 0; c < CE_REG; c++) z[c] = c < n ? logits[(size_t)(b + min(c, n - 1)) * N + p] : -INFINITY;
-            float m = z[0];
+                for (int c = 0; c < CE_REG; c++) z[c] = c < n ? logits[(size_t)(b + min(c, n - 1)) * N + p] : -INFINITY;
+                float m = z[0];
 #pragma unroll
-            for (int c = 1; c < CE_REG; c++) m = fmaxf(m, z[c]);
-            float s = 0.f, picked = 0.f;
+                for (int c = 1; c < CE_REG; c++) m = fmaxf(m, z[c]);
+                float s = 0.f, picked = 0.f;
 #pragma unroll
-            for (int c = 0; c < CE_REG; c++) {
-                picked = c == lab ? z[c] : picked;
-                z[c] = c < n ? expf(z[c] - m) : 0.f;
-                s += z[c];
-            }
-            if (GRAD) {
-                const float inv_s = 1.0f / s;
-                if (live) {
+                for (int c = 0; c < CE_REG; c++) {
+                    picked = c == lab ? z[c] : picked;
+                    z[c] = c < n ? expf(z[c] - m) : 0.f;
+                    s += z[c];
+                }
+                if (GRAD) {
+                    const float inv_s = 1.0f / s;
+                    if (live) {
 #pragma unroll
-                    for (int c = 0; c < CE_REG; c++)
-                        if (c < n) {
-                            const size_t gi = (size_t)(b + c) * N + p;
-                            const float tv = (z[c] * inv_s - (c == lab ? 1.f : 0.f)) * sc;
-                            grad[gi] = add_grad ? fmaf(add_grad[gi], as, tv) : tv;
-                        }
+                        for (int c = 0; c < CE_REG; c++)
+                            if (c < n) {
+                                const size_t gi = (size_t)(b + c) * N + p;
+                                const float tv = (z[c] * inv_s - (c == lab ? 1.f : 0.f)) * sc;
+                                grad[gi] = add_grad ? fmaf(add_grad[gi], as, tv) : tv;
+                            }
+                    }
+                } else {
+                    loss = valid ? (m + logf(s)) - picked : 0.f;
                 }
             } else {
-                loss = valid ? (m + logf(s)) - picked : 0.f;
+                // wide level: stream it (online log-sum-exp, second read from L2)
+                float m = -INFINITY, s = 0.f, picked = 0.f;
+                for (int c = 0; c < n; c++) {
+                    const float z = logits[(size_t)(b + c) * N + p];
+                    const float nm = fmaxf(m, z);
+                    s = s * expf(m - nm) + expf(z - nm);
+                    m = nm;
+                    picked = c == lab ? z : picked;
+                }
+                if (GRAD) {
+                    const float inv_s = 1.0f / s;
+                    if (live)
+                        for (int c = 0; c < n; c++) {
+                            const float z = logits[(size_t)(b + c) * N + p];
+                            const size_t gi = (size_t)(b + c) * N + p;
+                            const float tv = (expf(z - m) * inv_s - (c == lab ? 1.f : 0.f)) * sc;
+                            grad[gi] = add_grad ? fmaf(add_grad[gi], as, tv) : tv;
+                        }
+                } else {
+                    loss = valid ? (m + logf(s)) - picked : 0.f;
+                }
             }
-        } else {
-            // wide level: stream it (online log-sum-exp, second read from L2)
-            float m = -INFINITY, s = 0.f, picked = 0.f;
-            for (int c = 0; c < n; c++) {
-                const float z = logits[(size_t)(b + c) * N + p];
-                const float nm = fmaxf(m, z);
-                s = s * expf(m - nm) + expf(z - nm);
-                m = nm;
-                picked = c == lab ? z : picked;
-            }
-            if (GRAD) {
-                const float inv_s = 1.0f / s;
-                if (live)
-                    for (int c = 0; c < n; c++) {
-                        const float z = logits[(size_t)(b + c) * N + p];
-                        const size_t gi = (size_t)(b + c) * N + p;
-                        const float tv = (expf(z - m) * inv_s - (c == lab ? 1.f : 0.f)) * sc;
-                        grad[gi] = add_grad ? fmaf(add_grad[gi], as, tv) : tv;
-                    }
-            } else {
-                loss = valid ? (m + logf(s)) - picked : 0.f;
-            }
-        }
-        lsum[l] = loss;
-        lcnt[l] = valid ? 1.f : 0.f;
-        covered_end = b + n;
-    }
-    if (GRAD) {
-        if (live)
-            for (int c = covered_end; c < K; c++) grad[(size_t)c * N + p] = add_grad ? add_grad[(size_t)c * N + p] * as : 0.f;   // channels behind the last level
-        return;
-    }
-    // one reduction for all levels: wave sums, then the four waves in a fixed order (counts are exact in fp32: <= 256 per block)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll 1
-    for (int l = 0; l < lv.n; l++) {
-        float a = lsum[l], c = lcnt[l];
+            if (!GRAD) {
+                // the wave's sums of this level, added into the wave's own row (counts are exact in fp32: <= 64 per add, <= 128 per row)
+                float a = loss, cnt = valid ? 1.f : 0.f;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            a += __shfl_xor(a, o, 64);
-            c += __shfl_xor(c, o, 64);
+                for (int o = 32; o > 0; o >>= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    cnt += __shfl_xor(cnt, o, 64);
+                }
+                if (lane == 0) {
+                    s_part[wv][l] += a;
+                    s_part[wv][HSR_LOSS_MAX_LEVELS + l] += cnt;
+                }
+            }
+            covered_end = b + n;
         }
-        if (lane == 0) {
-            s_part[wv][l] = a;
-            s_part[wv][HSR_LOSS_MAX_LEVELS + l] = c;
-        }
+        if (GRAD && live)
+            for (int c = covered_end; c < K; c++) grad[(size_t)c * N + p] = add_grad ? add_grad[(size_t)c * N + p] * as : 0.f;   // channels behind the last level
     }
+    if (GRAD) return;
     __syncthreads();
     if (threadIdx.x < 2 * HSR_LOSS_MAX_LEVELS) {
         const int k = threadIdx.x;
-        partials[(size_t)blockIdx.x * (2 * HSR_LOSS_MAX_LEVELS) + k] =
-            (k % HSR_LOSS_MAX_LEVELS) < lv.n ? ((s_part[0][k] + s_part[1][k]) + s_part[2][k]) + s_part[3][k] : 0.f;
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < TB / 64; w2++) v += s_part[w2][k];   // fixed order
+        partials[(size_t)blockIdx.x * (2 * HSR_LOSS_MAX_LEVELS) + k] = (k % HSR_LOSS_MAX_LEVELS) < lv.n ? v : 0.f;
     }
 }
 
@@ -1057,11 +1060,12 @@ extern "C" int hsr_loss_tree_ce_value(int K, int H, int W, int num_levels, const
         return HSR_ERR_INVALID_ARGUMENT;
     }
     const int N = H * W;
-    const int nb = (N + LB - 1) / LB;
+    constexpr int VB = 1024;
+    const int nb = (N + VB * CE_ITEMS - 1) / (VB * CE_ITEMS);
     rc = check_scratch("loss_tree_ce_value", scratch, scratch_bytes, hsr_loss_tree_ce_scratch_bytes(H, W) - 256);
     if (rc != HSR_OK) return rc;
     float* partials = reinterpret_cast<float*>(scratch);
-    tree_ce2_kernel<false><<<nb, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, nullptr, nullptr, nullptr, partials, nullptr, nullptr, 0.f);
+    tree_ce2_kernel<false, VB><<<nb, VB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, nullptr, nullptr, nullptr, partials, nullptr, nullptr, 0.f);
     tree_ce_finish_kernel<<<1, CEF_T, 0, stream>>>(partials, nb, num_levels, out_level_loss, out_inv_count);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
@@ -1081,7 +1085,7 @@ extern "C" int hsr_loss_tree_ce_grad(int K, int H, int W, int num_levels, const 
         return HSR_ERR_INVALID_ARGUMENT;
     }
     const int N = H * W;
-    tree_ce2_kernel<true><<<(N + LB - 1) / LB, LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, inv_count, upstream, out_grad, nullptr, add_grad,
+    tree_ce2_kernel<true, LB><<<(N + LB * CE_ITEMS - 1) / (LB * CE_ITEMS), LB, 0, stream>>>(logits, labels, N, K, lv, ignore_index, inv_count, upstream, out_grad, nullptr, add_grad,
                                                                 add_scale, add_host_scale);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
