@@ -305,8 +305,10 @@ __global__ __launch_bounds__(LB) void ssim_forward_kernel(const float* __restric
 // maps (which are zero outside the image)
 __global__ __launch_bounds__(LB) void ssim_backward_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
                                                            Gauss gw, const float* __restrict__ d_mu1, const float* __restrict__ d_s11,
-                                                           const float* __restrict__ d_s12, float inv_n, float* __restrict__ grad)
+                                                           const float* __restrict__ d_s12, float inv_n_host, const float* __restrict__ upstream,
+                                                           float* __restrict__ grad)
 {
+    const float inv_n = inv_n_host * (upstream ? upstream[0] : 1.0f);   // the node's incoming gradient, read on the device (hsr_loss_ssim_grad)
     __shared__ float s_in[3][SS_E][SS_E + 1];
     __shared__ float s_h[3][SS_E][SS_T + 1];
     const size_t plane = (size_t)blockIdx.z * H * W;
@@ -958,7 +960,98 @@ extern "C" int hsr_loss_ssim(int C, int H, int W, const float* img1, const float
     const float inv_n = (float)(1.0 / ((double)C * (double)N));
     ssim_forward_kernel<<<grid, LB, 0, stream>>>(img1, img2, H, W, win, d_mu1, d_s11, d_s12, partials);
     finish_kernel<<<1, LB, 0, stream>>>(partials, (int)tiles, 1, 1, nullptr, inv_n, out_ssim);
-    if (out_grad) ssim_backward_kernel<<<grid, LB, 0, stream>>>(img1, img2, H, W, win, d_mu1, d_s11, d_s12, inv_n, out_grad);
+    if (out_grad) ssim_backward_kernel<<<grid, LB, 0, stream>>>(img1, img2, H, W, win, d_mu1, d_s11, d_s12, inv_n, nullptr, out_grad);
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+namespace {
+Gauss ssim_window()
+{
+    // the reference's 1-D window: gaussian(11, 1.5) as float32, normalised in float32 (utils/slam_external.py:54-56)
+    Gauss win;
+    float sum = 0.f;
+    for (int x = 0; x < 11; x++) {
+        win.g[x] = (float)std::exp(-(double)((x - 5) * (x - 5)) / (2.0 * 1.5 * 1.5));
+        sum += win.g[x];
+    }
+    for (int x = 0; x < 11; x++) win.g[x] = win.g[x] / sum;
+    return win;
+}
+}  // namespace
+
+// Two-pass form for an autograd node: the value pass leaves the three partial-derivative maps in `maps` (3 * C * H * W floats, the
+// caller's: they must live until the gradient pass), the gradient pass is the adjoint correlation times the upstream gradient.
+extern "C" int hsr_loss_ssim_value(int C, int H, int W, const float* img1, const float* img2, float* out_ssim, float* maps, char* scratch,
+                                   size_t scratch_bytes, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (C < 1 || H < 1 || W < 1 || !img1 || !img2 || !out_ssim) {
+        hsr_set_error("loss_ssim_value: invalid sizes C=%d H=%d W=%d or NULL img1/img2/out_ssim", C, H, W);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    const size_t N = (size_t)H * W;
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
+    const size_t tiles = (size_t)grid.x * grid.y * C;
+    int rc = check_scratch("loss_ssim_value", scratch, scratch_bytes, align256(tiles * sizeof(float)));
+    if (rc != HSR_OK) return rc;
+    float* partials = reinterpret_cast<float*>(scratch);
+    const float inv_n = (float)(1.0 / ((double)C * (double)N));
+    ssim_forward_kernel<<<grid, LB, 0, stream>>>(img1, img2, H, W, ssim_window(), maps, maps ? maps + (size_t)C * N : nullptr,
+                                                 maps ? maps + 2 * (size_t)C * N : nullptr, partials);
+    finish_kernel<<<1, LB, 0, stream>>>(partials, (int)tiles, 1, 1, nullptr, inv_n, out_ssim);
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+extern "C" int hsr_loss_ssim_grad(int C, int H, int W, const float* img1, const float* img2, const float* maps, const float* upstream,
+                                  float* out_grad, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (C < 1 || H < 1 || W < 1 || !img1 || !img2 || !maps || !out_grad) {
+        hsr_set_error("loss_ssim_grad: invalid sizes C=%d H=%d W=%d or NULL img1/img2/maps/out_grad", C, H, W);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    const size_t N = (size_t)H * W;
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
+    const float inv_n = (float)(1.0 / ((double)C * (double)N));
+    ssim_backward_kernel<<<grid, LB, 0, stream>>>(img1, img2, H, W, ssim_window(), maps, maps + (size_t)C * N, maps + 2 * (size_t)C * N, inv_n,
+                                                  upstream, out_grad);
+    HSR_HIP_CHECK(hipGetLastError());
+    return HSR_OK;
+}
+
+// d loss / d pred of hsr_loss_l1 as its own pass, times the upstream gradient (DEVICE float, NULL = 1): sums with or without a mask and the
+// unmasked mean — the masked mean needs the selection count of the value pass and keeps the one-pass form.
+__global__ __launch_bounds__(LB) void l1_grad_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const uint8_t* __restrict__ mask,
+                                                     int N, float host_scale, const float* __restrict__ upstream, float* __restrict__ grad)
+{
+    const size_t plane = (size_t)blockIdx.y * N;
+    const float scale = host_scale * (upstream ? upstream[0] : 1.0f);
+    for (int i = blockIdx.x * LB * L1_ITEMS + threadIdx.x, it = 0; it < L1_ITEMS; it++, i += LB) {
+        if (i >= N) break;
+        const bool sel = mask ? mask[i] != 0 : true;
+        const float d = pred[plane + i] - gt[plane + i];
+        grad[plane + i] = sel ? (d > 0.f ? scale : (d < 0.f ? -scale : 0.f)) : 0.f;
+    }
+}
+
+extern "C" int hsr_loss_l1_grad(int C, int H, int W, const float* pred, const float* gt, const uint8_t* mask, int reduction,
+                                const float* upstream, float* out_grad, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (C < 1 || H < 1 || W < 1 || (size_t)H * W > 0x7fffffffu || !pred || !gt || !out_grad) {
+        hsr_set_error("loss_l1_grad: invalid sizes C=%d H=%d W=%d or NULL pred/gt/out_grad", C, H, W);
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    if (reduction != HSR_LOSS_SUM && !(reduction == HSR_LOSS_MEAN && !mask)) {
+        hsr_set_error("loss_l1_grad: sums (masked or not) and the unmasked mean only; the masked mean's gradient comes from hsr_loss_l1");
+        return HSR_ERR_INVALID_ARGUMENT;
+    }
+    const int N = H * W;
+    const int nb = (N + LB * L1_ITEMS - 1) / (LB * L1_ITEMS);
+    const float host_scale = reduction == HSR_LOSS_MEAN ? (float)(1.0 / ((double)C * N)) : 1.0f;
+    l1_grad_kernel<<<dim3(nb, C), LB, 0, stream>>>(pred, gt, mask, N, host_scale, upstream, out_grad);
     HSR_HIP_CHECK(hipGetLastError());
     return HSR_OK;
 }

@@ -26,6 +26,12 @@ _lib.hsr_loss_l1.restype = _ci
 _lib.hsr_loss_l1.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _sz, _vp]
 _lib.hsr_loss_ssim.restype = _ci
 _lib.hsr_loss_ssim.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+_lib.hsr_loss_l1_grad.restype = _ci
+_lib.hsr_loss_l1_grad.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp]
+_lib.hsr_loss_ssim_value.restype = _ci
+_lib.hsr_loss_ssim_value.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+_lib.hsr_loss_ssim_grad.restype = _ci
+_lib.hsr_loss_ssim_grad.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.hsr_loss_tree_ce.restype = _ci
 _lib.hsr_loss_tree_ce.argtypes = [_ci, _ci, _ci, _ci, C.POINTER(_ci), C.POINTER(C.c_float), _vp, _vp, _ci, _vp, _vp, _vp, _sz, _vp]
 
@@ -85,7 +91,10 @@ class _L1(torch.autograd.Function):
                 raise RuntimeError("hsr_utils.losses: mask must be [H,W] or [1,H,W] (it is tiled over the channels)")
             m = (m if m.dtype == torch.bool else m != 0).to(torch.uint8).contiguous()
         out = torch.empty(1, dtype=torch.float32, device=dev)
-        grad = torch.empty_like(p) if pred.requires_grad else None
+        # sums and the unmasked mean: value now, gradient in backward() times the incoming gradient (hsr_loss_l1_grad); the masked mean's
+        # gradient needs the selection count of this pass and is stashed here, rescaled there
+        ctx.two_pass = bool(pred.requires_grad) and (int(reduction) == SUM or m is None)
+        grad = torch.empty_like(p) if (pred.requires_grad and not ctx.two_pass) else None
         sc = _scratch(Cc, H, W, dev)
         with torch.cuda.device(dev):
             rc = _lib.hsr_loss_l1(Cc, H, W, p.data_ptr(), g.data_ptr(), None if m is None else m.data_ptr(), int(reduction),
@@ -93,11 +102,26 @@ class _L1(torch.autograd.Function):
         if rc < 0:
             _glue._fail(rc, "hsr_loss_l1")
         ctx.grad = None if grad is None else grad.view(shape)
+        if ctx.two_pass:
+            ctx.save_for_backward(p, g, m if m is not None else torch.empty(0, device=dev))
+            ctx.meta = (Cc, H, W, int(reduction), m is not None, tuple(shape))
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
-        return (None if ctx.grad is None else ctx.grad * g), None, None, None
+        if not ctx.two_pass or g is None:
+            return (None if ctx.grad is None or g is None else ctx.grad * g), None, None, None
+        p, gt, m = ctx.saved_tensors
+        Cc, H, W, reduction, has_mask, shape = ctx.meta
+        dev = p.device
+        gg = g.to(device=dev, dtype=torch.float32).contiguous()
+        grad = torch.empty_like(p)
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_l1_grad(Cc, H, W, p.data_ptr(), gt.data_ptr(), m.data_ptr() if has_mask else None, reduction, gg.data_ptr(),
+                                       grad.data_ptr(), _stream(dev))
+        if rc < 0:
+            _glue._fail(rc, "hsr_loss_l1_grad")
+        return grad.view(shape), None, None, None
 
 
 class _SSIM(torch.autograd.Function):
@@ -110,19 +134,34 @@ class _SSIM(torch.autograd.Function):
         Cc, H, W = a.shape
         dev = a.device
         out = torch.empty(1, dtype=torch.float32, device=dev)
-        grad = torch.empty_like(a) if img1.requires_grad else None
-        sc = _scratch(Cc, H, W, dev)
+        # value pass now (it leaves the three partial-derivative maps), the adjoint correlation in backward() times the incoming gradient
+        maps = torch.empty((3, Cc, H, W), dtype=torch.float32, device=dev) if img1.requires_grad else None
+        sc = torch.empty(4096 + 4 * Cc * ((H + 31) // 32) * ((W + 31) // 32), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            rc = _lib.hsr_loss_ssim(Cc, H, W, a.data_ptr(), b.data_ptr(), out.data_ptr(), None if grad is None else grad.data_ptr(),
-                                    sc.data_ptr(), sc.numel(), _stream(dev))
+            rc = _lib.hsr_loss_ssim_value(Cc, H, W, a.data_ptr(), b.data_ptr(), out.data_ptr(), None if maps is None else maps.data_ptr(),
+                                          sc.data_ptr(), sc.numel(), _stream(dev))
         if rc < 0:
-            _glue._fail(rc, "hsr_loss_ssim")
-        ctx.grad = None if grad is None else grad.view(shape)
+            _glue._fail(rc, "hsr_loss_ssim_value")
+        ctx.want = maps is not None
+        if ctx.want:
+            ctx.save_for_backward(a, b, maps)
+            ctx.meta = (Cc, H, W, tuple(shape))
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
-        return (None if ctx.grad is None else ctx.grad * g), None
+        if not ctx.want or g is None:
+            return None, None
+        a, b, maps = ctx.saved_tensors
+        Cc, H, W, shape = ctx.meta
+        dev = a.device
+        gg = g.to(device=dev, dtype=torch.float32).contiguous()
+        grad = torch.empty_like(a)
+        with torch.cuda.device(dev):
+            rc = _lib.hsr_loss_ssim_grad(Cc, H, W, a.data_ptr(), b.data_ptr(), maps.data_ptr(), gg.data_ptr(), grad.data_ptr(), _stream(dev))
+        if rc < 0:
+            _glue._fail(rc, "hsr_loss_ssim_grad")
+        return grad.view(shape), None
 
 
 class _TreeCE(torch.autograd.Function):

@@ -64,6 +64,18 @@ int hsr_loss_tracking_grad(int C, int H, int W, const float* im, const float* gt
 int hsr_loss_ssim(int C, int H, int W, const float* img1, const float* img2, float* out_ssim, float* out_grad, char* scratch,
                   size_t scratch_bytes, void* stream);
 
+/* The same two heads in two passes, for an autograd node (hsr_utils/losses.py): value now, gradient when autograd asks — multiplied by
+ * the node's incoming gradient read from DEVICE memory (`upstream`, NULL = 1), so that no stashed gradient is rescaled afterwards.
+ * hsr_loss_l1_grad: sums (masked or not) and the unmasked mean (the masked mean's gradient needs the selection count: hsr_loss_l1).
+ * hsr_loss_ssim_value writes the three partial-derivative maps into `maps` (3 * C * H * W floats owned by the caller, alive until
+ * hsr_loss_ssim_grad; NULL = value only); scratch: hsr_loss_scratch_bytes(C, H, W) is ample. */
+int hsr_loss_l1_grad(int C, int H, int W, const float* pred, const float* gt, const uint8_t* mask, int reduction, const float* upstream,
+                     float* out_grad, void* stream);
+int hsr_loss_ssim_value(int C, int H, int W, const float* img1, const float* img2, float* out_ssim, float* maps, char* scratch,
+                        size_t scratch_bytes, void* stream);
+int hsr_loss_ssim_grad(int C, int H, int W, const float* img1, const float* img2, const float* maps, const float* upstream, float* out_grad,
+                       void* stream);
+
 /* For level l = 0..num_levels-1 with channel range [sum(level_sizes[:l]), +level_sizes[l]) of `logits` ([K,H,W]):
  *   out_level_loss[l] = CrossEntropyLoss()(logits[range] viewed as [H*W, n_l], labels[l])      (mean over pixels whose
  * label != ignore_index; torch's default ignore_index is -100).  `labels` is int64 [>= num_levels, H, W] (the reference
